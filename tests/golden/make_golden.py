@@ -1,0 +1,392 @@
+"""Generate the golden fixtures in tests/golden/*.npz by RUNNING THE REFERENCE (imported from /root/reference).
+
+Run by hand in the build container only:   python tests/golden/make_golden.py
+The reference never travels: only the resulting data (weights / inputs / expected outputs at reduced dims) is
+committed.  Reduced dims are possible because every reference class takes its sizes from config objects
+(SURVEY.md section 7 step 1).  The fixtures pin `oracle/tdc_oracle.py`; the oracle then checks the HIP path.
+
+Fixtures written:
+  qformer_small.npz     tdc/Qformer.py BertModel + query_proj/vision_proj on one 8-frame chunk (a12-a18)
+  sva_small.npz         tdc/vision_sampler.py VisionTokenSampler incl. mask geometry (a7, a8)
+  siglip_small.npz      SiglipVisionTower._forward on a tiny HF SiglipVisionModel (a3)
+  dino_small.npz        DinoVisionTower._forward on a tiny HF Dinov2Model (a4)
+  pipeline_T40.npz      full prepare_inputs_labels_for_multimodal, T=40 square frames (a1-a21, Q-Former active)
+  pipeline_T10_land.npz full path, T=10 frames 360x640 (all static; exercises the (H,W)/(W,H) quirk D8)
+  pipeline_T260.npz     full path, T=260 (224-frame cap a1/a5 + budget clipping a19) with a small max length
+  manifest.json         shapes / versions / seeds
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shims  # noqa: E402
+import synth  # noqa: E402
+
+VOCAB_BERT = 300
+BERT_KW = dict(hidden_size=64, num_hidden_layers=4, num_attention_heads=4, intermediate_size=128,
+               vocab_size=VOCAB_BERT, max_position_embeddings=64)
+
+from transformers import Dinov2Config, SiglipVisionConfig  # noqa: E402
+
+DINO_CFG = Dinov2Config(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, image_size=70, patch_size=14,
+                        mlp_ratio=4, use_swiglu_ffn=True, layerscale_value=1.0)
+SIGLIP_CFG = SiglipVisionConfig(hidden_size=48, intermediate_size=80, num_hidden_layers=2, num_attention_heads=4,
+                                image_size=126, patch_size=14)
+
+arch, Q, vs = ref_shims.install(bert_cfg_kwargs=BERT_KW, dino_cfg=DINO_CFG)
+# fake tokenizer must agree with the small vocab
+from transformers import BertTokenizer  # noqa: E402
+
+BertTokenizer.from_pretrained = classmethod(lambda cls, *a, **k: ref_shims.FakeBertTokenizer(VOCAB_BERT))
+from transformers import Dinov2Model, SiglipVisionModel  # noqa: E402
+
+H_LLM = 96
+C_VIS = 64
+LLM_VOCAB = 160000  # ids up to 151643 must embed; only rows actually used are saved
+
+
+def sd_np(module, prefix=""):
+    return {prefix + k: v.detach().cpu().numpy() for k, v in module.state_dict().items()}
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print("wrote", name, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+# ------------------------------------------------------------------------------------------------------------
+def make_config(**over):
+    cfg = types.SimpleNamespace(
+        mm_vision_tower_aux_list=["siglip/CLIP-ViT-SO400M-14-384", "facebook/dinov2-giant-res378"],
+        mm_vision_tower_aux_token_len_list=[64, 64],
+        mm_projector_type="sva", vision_hidden_size=C_VIS, num_query_group=1, query_num_list=[16],
+        image_token_len=16, connector_only=True, connector_depth=2, hidden_size=H_LLM, model_type="qwen2",
+        tokenizer_model_max_length=8192, inference_max_length=16, tokenizer_padding_side="right",
+        context_token_num=4, mm_vision_select_layer=-2, mm_vision_select_feature="patch", lowres_token=8,
+        unfreeze_mm_vision_tower=False,
+    )
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+class StubBase(nn.Module):
+    """Minimal host for the mixin: config, embed_tokens, dtype, device."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.embed_tokens = nn.Embedding(LLM_VOCAB, config.hidden_size)
+
+    @property
+    def dtype(self):
+        return torch.float32
+
+    @property
+    def device(self):
+        return torch.device("cpu")
+
+
+def build_lm(cfg, seed=0):
+    torch.manual_seed(seed)
+
+    class StubModel(arch.CambrianMetaModel, StubBase):
+        pass
+
+    class StubLM(nn.Module, arch.CambrianMetaForCausalLM):
+        def __init__(self, config):
+            nn.Module.__init__(self)
+            self.config = config
+            self.model = StubModel(config)
+
+        def get_model(self):
+            return self.model
+
+        @property
+        def device(self):
+            return torch.device("cpu")
+
+    lm = StubLM(cfg)
+    m = lm.model
+    # towers: attach tiny random-init HF models (wrappers' load_model needs the hub)
+    sig, dino = m.vision_tower_aux_list
+    sig.vision_tower = SiglipVisionModel(SIGLIP_CFG)
+    sig.is_loaded = True
+    sig._interp_size = 64
+    dino.vision_tower = Dinov2Model(DINO_CFG)
+    dino.is_loaded = True
+    dino._interp_size = 64
+    dino._image_size = 126
+    # mm_projector_aux_i were sized for the real towers at construction (delay_load => 1152 / giant): rebuild
+    # them for the tiny towers with the same module structure as tdc/cambrian_arch.py:84-89
+    for i, dv in enumerate((SIGLIP_CFG.hidden_size, DINO_CFG.hidden_size)):
+        setattr(m, "mm_projector_aux_%d" % i, nn.Sequential(
+            nn.Linear(dv, cfg.vision_hidden_size), nn.GELU(),
+            nn.Linear(cfg.vision_hidden_size, cfg.vision_hidden_size), nn.LayerNorm(cfg.vision_hidden_size)))
+    # make LayerNorm / LayerScale / biases non-trivial so the fixtures can detect a swapped or dropped parameter
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for name, p in lm.named_parameters():
+            if p.ndim == 1:
+                if "LayerNorm.weight" in name or "norm" in name and name.endswith("weight") or "lambda1" in name \
+                        or name.endswith(".3.weight") or name.endswith(".0.weight"):
+                    p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
+                elif name.endswith("bias"):
+                    p.copy_(0.1 * torch.randn(p.shape, generator=g))
+        for tower in m.vision_tower_aux_list:
+            for name, p in tower.vision_tower.named_parameters():
+                if p.ndim == 1 and (name.endswith("weight") or "lambda1" in name):
+                    p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
+                elif p.ndim == 1:
+                    p.copy_(0.1 * torch.randn(p.shape, generator=g))
+                elif p.ndim == 2 and "position" not in name:
+                    p.copy_(p * 3.0)
+        m.image_newline.copy_(torch.randn(m.image_newline.shape, generator=g))
+        m.embed_tokens.weight.copy_(0.5 * torch.randn(m.embed_tokens.weight.shape, generator=g))
+    lm.eval()
+    return lm
+
+
+def lm_state(lm):
+    """Reference-named state dict (keys as in SURVEY 8(b)), without the dead LM head and with only used embeds."""
+    out = {}
+    for k, v in lm.state_dict().items():
+        if ".Qformer.cls." in k or k.endswith("position_ids"):
+            continue
+        if k == "model.embed_tokens.weight":
+            continue
+        out[k] = v.detach().cpu().numpy()
+    # the towers live in a plain python list (tdc/cambrian_arch.py:62), so they are not in state_dict()
+    for i, tower in enumerate(lm.model.vision_tower_aux_list):
+        for k, v in tower.vision_tower.state_dict().items():
+            if k.startswith("head.") or "post_layernorm" in k or "mask_token" in k:
+                continue  # unused by the path (siglip pooling head / post-LN: siglip_encoder.py:73-76)
+            out["model.vision_tower_aux_list.%d.vision_tower.%s" % (i, k)] = v.detach().cpu().numpy()
+    return out
+
+
+def run_pipeline(name, T, image_size, prompt, cfg_over=None, seed=0, px=126, video_indices=(None,),
+                 keep_intermediates=True):
+    cfg = make_config(**(cfg_over or {}))
+    lm = build_lm(cfg, seed)
+    basis, coef = synth.make_basis_and_coef(T, px, seed=1234 + seed)
+    vid = torch.from_numpy(synth.video_from_basis(basis, coef))
+    vid_dino = vid + 0.01
+    images = [vid.unsqueeze(0), vid_dino.unsqueeze(0)]
+    # input ids: text, <image>=-200, text
+    ids = torch.tensor([[1001, 1002, 1003, -200, 1004, 1005, 1006, 1007, 1008]], dtype=torch.long)
+    used_ids = sorted(set(int(i) for i in ids[0] if i >= 0))
+    cap = {}
+    hooks = []
+
+    def grab(key):
+        def fn(mod, inp, out):
+            cap.setdefault(key, []).append(out.detach().clone())
+        return fn
+
+    m = lm.model
+    hooks.append(m.vision_tower_aux_list[0].register_forward_hook(grab("siglip_feat")))
+    hooks.append(m.vision_tower_aux_list[1].register_forward_hook(grab("dino_feat")))
+    hooks.append(m.mm_projector_aux_0.register_forward_hook(grab("aux0")))
+    hooks.append(m.mm_projector_aux_1.register_forward_hook(grab("aux1")))
+    hooks.append(m.vision_sampler_0.register_forward_hook(grab("sva_out")))
+    hooks.append(m.mm_projector.register_forward_hook(grab("mm_proj")))
+    hooks.append(m.vision_proj.register_forward_hook(grab("vision_proj")))
+    seg_cap = {}
+    orig_adapt = lm.adapt_segment
+
+    def adapt_wrap(*a, **k):
+        r = orig_adapt(*a, **k)
+        seg_cap["split_sizes"] = list(r[1])
+        seg_cap["selected"] = [x.clone() for x in r[3]]
+        seg_cap["seg"] = [x.clone() for x in r[4]]
+        return r
+
+    lm.adapt_segment = adapt_wrap
+    with torch.inference_mode():
+        out = lm.prepare_inputs_labels_for_multimodal(
+            ids, None, None, None, None, images, image_sizes=[image_size],
+            video_indices=(list(video_indices) if video_indices is not None else None),
+            prompts=[prompt], audios=[None])
+    for h in hooks:
+        h.remove()
+    inputs_embeds = out[4]
+    final_size = out[8]
+    arrs = dict(
+        video_basis=basis, video_coef=coef,
+        input_ids=ids.numpy(), image_size=np.array(image_size), prompt_ids=np.array(
+            ref_shims.prompt_to_ids(prompt, VOCAB_BERT)),
+        used_embed_ids=np.array(used_ids),
+        used_embed_rows=m.embed_tokens.weight[used_ids].detach().numpy(),
+        out_inputs_embeds=inputs_embeds.numpy(),
+        out_final_size=np.array(final_size),
+        out_seg_indices=seg_cap["seg"][0].numpy(), out_selected=seg_cap["selected"][0].numpy(),
+        out_split_size=np.array(seg_cap["split_sizes"]),
+        out_siglip_feat=torch.cat(cap["siglip_feat"]).numpy(), out_dino_feat=torch.cat(cap["dino_feat"]).numpy(),
+        out_aux0=cap["aux0"][0].numpy(), out_aux1=cap["aux1"][0].numpy(),
+        out_sva=cap["sva_out"][0].reshape(len(seg_cap["selected"][0]), -1, cfg.vision_hidden_size).numpy(), out_mm_proj=cap["mm_proj"][0].numpy(),
+        cfg_json=np.array(json.dumps({k: v for k, v in vars(cfg).items()})),
+    )
+    if "vision_proj" in cap:
+        arrs["out_vision_proj_first"] = cap["vision_proj"][0].numpy()
+        arrs["n_qformer_calls"] = np.array(len(cap["vision_proj"]))
+    else:
+        arrs["n_qformer_calls"] = np.array(0)
+    if not keep_intermediates:
+        for k in ("out_siglip_feat", "out_dino_feat", "out_aux0", "out_aux1", "out_sva", "out_mm_proj"):
+            arrs[k] = arrs[k][::16]  # every 16th frame only
+    for k, v in lm_state(lm).items():
+        arrs["w::" + k] = v
+    save(name, **arrs)
+    return dict(T=T, image_size=list(image_size), inputs_embeds=list(inputs_embeds.shape),
+                n_qformer_calls=int(arrs["n_qformer_calls"]), seg=seg_cap["seg"][0].tolist())
+
+
+# ------------------------------------------------------------------------------------------------------------
+def make_qformer():
+    torch.manual_seed(3)
+    from transformers import BertConfig
+    cfg = BertConfig(**BERT_KW)
+    cfg.encoder_width = H_LLM
+    cfg.add_cross_attention = True
+    cfg.cross_attention_freq = 2
+    cfg.query_length = 4
+    qf = Q.BertLMHeadModel(cfg).eval()
+    query_proj = nn.Linear(H_LLM, 64)
+    vision_proj = nn.Linear(64, H_LLM)
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for n, p in list(qf.named_parameters()) + list(query_proj.named_parameters()) + list(
+                vision_proj.named_parameters()):
+            if p.ndim == 1 and "LayerNorm.weight" in n:
+                p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
+            elif p.ndim == 1:
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+            else:
+                p.copy_(p * 4.0)  # BERT init std 0.02 -> make attention non-uniform
+    K, N, L = 4, 21, 5
+    chunk = torch.randn(L + 1, N, H_LLM, generator=g)
+    ids = torch.tensor([ref_shims.prompt_to_ids("what happens in the video ?", VOCAB_BERT)])
+    with torch.no_grad():
+        # follows tdc/cambrian_arch.py:1629-1667 verbatim in call structure
+        key_frame = chunk[0].unsqueeze(0).repeat_interleave(L, dim=0)
+        qt = torch.nn.functional.adaptive_avg_pool1d(key_frame.permute(2, 0, 1), K).permute(1, 2, 0)
+        qt = query_proj(qt).expand(L, -1, -1)
+        out = qf.bert(input_ids=ids.expand(L, -1), query_embeds=qt, encoder_hidden_states=chunk[1:],
+                      encoder_attention_mask=torch.ones(L, N, dtype=torch.long), use_cache=False, return_dict=True)
+        last = out.last_hidden_state
+        comp = torch.nn.functional.normalize(vision_proj(last[:, :K]), dim=-1)
+        out_nt = qf.bert(input_ids=None, query_embeds=qt, encoder_hidden_states=chunk[1:],
+                         encoder_attention_mask=torch.ones(L, N, dtype=torch.long), use_cache=False,
+                         return_dict=True).last_hidden_state
+    arrs = dict(chunk=chunk.numpy(), prompt_ids=ids[0].numpy(), K=np.array(K), out_query_tokens=qt[0].numpy(),
+                out_last_hidden=last.numpy(), out_compressed=comp.numpy(), out_last_hidden_notext=out_nt.numpy())
+    for k, v in sd_np(qf.bert, "Qformer.bert.").items():
+        if not k.endswith("position_ids"):
+            arrs["w::" + k] = v
+    for k, v in sd_np(query_proj, "query_proj.").items():
+        arrs["w::" + k] = v
+    for k, v in sd_np(vision_proj, "vision_proj.").items():
+        arrs["w::" + k] = v
+    save("qformer_small.npz", **arrs)
+
+
+def make_sva():
+    torch.manual_seed(5)
+    sampler = vs.VisionTokenSampler(C_VIS, C_VIS, [C_VIS, C_VIS], [2, 2], C_VIS, 2).eval()
+    g = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        for n, p in sampler.named_parameters():
+            if p.ndim == 1 and n.endswith("weight"):
+                p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
+            elif p.ndim == 1:
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+    T, side = 3, 4
+    aux0 = torch.randn(T, 64, C_VIS, generator=g)
+    aux1 = torch.randn(T, 64, C_VIS, generator=g)
+    vq = torch.randn(1, C_VIS, generator=g)
+    ctx = aux0.mean(1).view(T, 1, 1, -1)
+    # use the reference's own rearrange + mask code on a stub `self` (cambrian_arch.py:601-695)
+    stub = types.SimpleNamespace()
+    image_sizes = [(384, 384), (360, 640), (640, 200)]
+    feats, masks = arch.CambrianMetaForCausalLM.rearrange_vision_tower_features_inference(
+        stub, [aux0, aux1], side, image_sizes)
+    q = vq[0].view(1, 1, 1, -1).expand(T, side * side, -1, -1).flatten(0, 1)
+    c = ctx.expand(-1, side * side, 1, -1).flatten(0, 1)
+    with torch.no_grad():
+        out = sampler(q, c, *feats, *masks).view(T, side * side, -1)
+    arrs = dict(aux0=aux0.numpy(), aux1=aux1.numpy(), vision_query=vq.numpy(), image_sizes=np.array(image_sizes),
+                out=out.numpy(), out_mask0=masks[0].numpy(), out_mask1=masks[1].numpy())
+    for k, v in sd_np(sampler, "vision_sampler_0.").items():
+        arrs["w::" + k] = v
+    save("sva_small.npz", **arrs)
+
+
+def make_towers():
+    torch.manual_seed(7)
+    cfg = make_config()
+    from tdc.multimodal_encoder.builder import build_vision_tower_aux_list
+    sig, dino = build_vision_tower_aux_list(cfg, delay_load=True)
+    sig.vision_tower = SiglipVisionModel(SIGLIP_CFG).eval()
+    sig.is_loaded = True
+    sig._interp_size = 64
+    dino.vision_tower = Dinov2Model(DINO_CFG).eval()
+    dino.is_loaded = True
+    dino._interp_size = 64
+    dino._image_size = 126
+    g = torch.Generator().manual_seed(8)
+    with torch.no_grad():
+        for mod in (sig, dino):
+            for n, p in mod.named_parameters():
+                if p.ndim == 1 and ("norm" in n.lower() and n.endswith("weight") or "lambda1" in n):
+                    p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
+                elif p.ndim == 1:
+                    p.copy_(0.1 * torch.randn(p.shape, generator=g))
+                elif p.ndim == 2 and "position" not in n:
+                    p.copy_(p * 3.0)
+    px = torch.rand(3, 3, 126, 126, generator=g) * 2 - 1
+    with torch.no_grad():
+        so = sig(px)
+        do = dino(px)
+        s_hidden = sig.vision_tower(px, output_hidden_states=True).hidden_states[-1]
+    a = dict(pixels=px.numpy(), out=so.numpy(), out_pre_interp=s_hidden.numpy())
+    for k, v in sd_np(sig.vision_tower, "").items():
+        if "head." in k or "post_layernorm" in k:
+            continue
+        a["w::" + k] = v
+    save("siglip_small.npz", **a)
+    a = dict(pixels=px.numpy(), out=do.numpy(),
+             out_pre_interp=dino.vision_tower(px).last_hidden_state.detach().numpy())
+    for k, v in sd_np(dino.vision_tower, "").items():
+        if "mask_token" in k:
+            continue
+        a["w::" + k] = v
+    save("dino_small.npz", **a)
+
+
+if __name__ == "__main__":
+    import transformers
+    man = dict(torch=torch.__version__, transformers=transformers.__version__, reference="Hoar012/TDC-Video @ 2025-08-29",
+               bert=BERT_KW, H_LLM=H_LLM, C_VIS=C_VIS)
+    make_qformer()
+    make_sva()
+    make_towers()
+    man["pipeline_T40"] = run_pipeline("pipeline_T40.npz", 40, (384, 384), "what happens in the video ?")
+    man["pipeline_T10_land"] = run_pipeline("pipeline_T10_land.npz", 10, (360, 640), "describe the clip", seed=1)
+    man["pipeline_T260"] = run_pipeline("pipeline_T260.npz", 260, (384, 384), "summarise", seed=2,
+                                        cfg_over=dict(tokenizer_model_max_length=2100), px=126,
+                                        # generate() passes [None], which makes the reference raise TypeError at
+                                        # cambrian_arch.py:919 as soon as the frame cap triggers; the cap path is
+                                        # only reachable with video_indices=None (direct call)
+                                        video_indices=None, keep_intermediates=False)
+    with open(os.path.join(HERE, "manifest.json"), "w") as f:
+        json.dump(man, f, indent=1)
+    print(json.dumps(man, indent=1))
