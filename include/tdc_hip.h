@@ -1,0 +1,142 @@
+/* tdc_hip.h — C ABI of libtdc_hip.so: the MI355X (gfx950) implementation of TDC-Video's video-encoding hot path.
+ *
+ * The reference (Hoar012/TDC-Video) is 100 % Python and has no FFI layer; its boundary for this path is the Python
+ * mixin `CambrianMetaForCausalLM.{encode_images, prepare_inputs_labels_for_multimodal}` (tdc/cambrian_arch.py:698,
+ * :864).  Each entry point below replaces the eager-op sequence of one stage of that function; the citation next to
+ * it names the reference lines it replaces.  `tdc-video_amd/` (Python) marshals torch tensors' data_ptr() into these
+ * calls; INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the name ends in `_host`; nothing is allocated inside a call
+ *    (composite calls take a caller-provided workspace; query its size with the matching *_workspace_bytes);
+ *  - `stream` is a hipStream_t passed as void*; calls only enqueue work (no synchronisation);
+ *  - return value: 0 on success, otherwise a hipError_t / negative TDC_E* code (message on stderr);
+ *  - 16-bit tensors are fp16 (TDC_F16) or bf16 (TDC_BF16), accumulation / LayerNorm / softmax / GELU are fp32;
+ *  - activation matrices are row-major [rows, ld] with ld = round_up(cols, 64) and ZERO pad columns; weights are
+ *    nn.Linear layout [out, in] padded the same way (prepared once by tdc-video_amd/weights.py).
+ */
+#ifndef TDC_HIP_H
+#define TDC_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TDC_F16 0
+#define TDC_BF16 1
+
+#define TDC_ACT_NONE 0
+#define TDC_ACT_GELU_ERF 1   /* nn.GELU() default, ACT2FN["gelu"]          */
+#define TDC_ACT_GELU_TANH 2  /* "gelu_pytorch_tanh" (SigLIP MLP)            */
+#define TDC_ACT_SWIGLU 3     /* silu(x1)*x2 on interleaved (x1,x2) columns  */
+
+#define TDC_E_BADARG (-2)
+#define TDC_E_WORKSPACE (-3)
+
+/* row(m) = (m / seg) * stride + off + (m % seg) * inner ; identity when seg == 0 */
+typedef struct { int seg, stride, off, inner; } tdc_rowmap;
+
+/* C[c_map(m), n] = act(sum_k A[a_map(m), k] * W[n, k] + bias[n]) + res[r_map(m), n]        (nn.Linear + epilogue)
+ * K % 64 == 0, N % 4 == 0 (N % 8 == 0 for SWIGLU, output col = n/2).  Replaces every nn.Linear on the path. */
+typedef struct {
+    const void* A; int lda;
+    const void* W; int ldw;
+    void* C; int ldc;
+    const float* bias;
+    const void* res; int ldres;
+    int M, N, K;
+    int dtype, out_f32, res_f32, act;
+    tdc_rowmap a_map, c_map, r_map;
+} tdc_gemm_desc;
+int tdc_gemm(const tdc_gemm_desc* d, void* stream);
+
+/* LayerNorm over `cols` real columns of x [rows, ldx] (fp32 or 16-bit), optional additive table before the norm:
+ * x'[r] = x[r] + add[(r % add_period) mapped by add_mode]; y = LN(x') * gamma + beta.  Writes y16 (16-bit, pad
+ * columns zeroed, may be NULL) and/or y32 (fp32, may alias x, may be NULL).
+ * add_mode 0: table row = r % add_period; 1: SVA 2x2 window position ((y&1)*2 + (x&1)) of token r % add_period on a
+ * sqrt(add_period)-wide grid (tdc/vision_sampler.py:375-384). */
+typedef struct {
+    const void* x; int ldx; int x_f32;
+    void* y16; int ldy16;
+    float* y32; int ldy32;
+    const float* gamma; const float* beta; float eps;
+    const float* add; int ldadd; int add_period; int add_mode;
+    int rows, cols, dtype;
+} tdc_ln_desc;
+int tdc_layernorm(const tdc_ln_desc* d, void* stream);
+
+/* softmax(Q K^T * scale) V, no mask.  Q element (b, s, h, c) at q + b*q_bs + s*q_rs + h*head_dim + c (same for
+ * k, v, o).  head_dim <= 96.  Replaces HF SigLIP/DINOv2 attention (HF:models/siglip/modeling_siglip.py:273-308),
+ * BertSelfAttention self and cross (tdc/Qformer.py:169-275). */
+typedef struct {
+    const void *q, *k, *v; void* o;
+    long long q_bs, k_bs, v_bs, o_bs;
+    int q_rs, k_rs, v_rs, o_rs;
+    int batch, heads, head_dim, sq, sk;
+    float scale; int dtype;
+} tdc_attn_desc;
+int tdc_attention(const tdc_attn_desc* d, void* stream);
+
+/* ---- small data-movement / reduction kernels ------------------------------------------------------------- */
+/* pixels [B,3,H,W] (fp32 or 16-bit) -> patches [B*gh*gw, ldp] 16-bit in conv-weight order (c,ky,kx), zero pad.
+ * Patch-embed conv as a GEMM (HF:models/siglip/modeling_siglip.py:124-130, dinov2/modeling_dinov2.py:140-151). */
+int tdc_im2col(const void* px, int px_f32, void* patches, int ldp, int B, int H, int W, int patch, int dtype,
+               void* stream);
+/* x32 [B, S, ld] rows `row` of every batch := vec[ld] (cls token + pos[0]) */
+int tdc_set_rows(float* x32, int ld, int B, int S, int row, const float* vec, void* stream);
+/* separable 2-tap resample of a token grid: x (fp32 or 16-bit) [B, tok_off + n_in*n_in, ldx] -> y 16-bit
+ * [B, n_out*n_out, ldy]; idx0/idx1/frac are device arrays [n_out] (bilinear, align_corners=False; built by host).
+ * siglip_encoder.py:43-69, dino_encoder.py:81-107 (and the cls drop of feature_select :66-79). */
+int tdc_resample_tokens(const void* x, int x_f32, int ldx, int tok_off, int n_in, void* y, int ldy, int n_out,
+                        const int* idx0, const int* idx1, const float* frac, int B, int cols, int dtype,
+                        void* stream);
+/* adjacent-frame cosine similarity on flattened features f [T, n] 16-bit: sims[t] = cos(f[t], f[t+1]), t < T-1
+ * (tdc/cambrian_arch.py:832-842); n % 8 == 0.  scratch: tdc_frame_cossim_scratch_floats(T) floats.  The reduction
+ * order is fixed (fp32), so the similarity ranking is reproducible run to run. */
+int tdc_frame_cossim(const void* f, long long n, int T, float* sims, float* scratch, int dtype, void* stream);
+size_t tdc_frame_cossim_scratch_floats(int T);
+/* mean over the token axis: x [B, P, ld] 16-bit -> y [B, ld] 16-bit (global context, cambrian_arch.py:1009) */
+int tdc_token_mean(const void* x, int P, int ld, void* y, int B, int dtype, void* stream);
+/* adaptive_avg_pool1d over the token axis: x [B, N, ld] -> y [B, K, ld] (cambrian_arch.py:1633-1637); rows of x for
+ * batch b start at x + src_row[b]*N*ld when src_row != NULL */
+int tdc_adaptive_pool_tokens(const void* x, int N, int ld, void* y, int K, int B, const int* src_row, int dtype,
+                             void* stream);
+/* out[i, :cols] = table_k[row] where (k,row) = src[2i], src[2i+1]; tables: up to 4 16-bit matrices with their ld.
+ * Used for unpad+newline (cambrian_arch.py:1195-1293) and token emission (:1668-1709). */
+typedef struct { const void* base[4]; int ld[4]; } tdc_gather_tables;
+int tdc_gather_rows(const tdc_gather_tables* t, const int* src, void* out, int ldo, int n, int cols, int dtype,
+                    void* stream);
+/* rows of x [rows, ld] 16-bit scaled to unit L2 norm over `cols` (F.normalize, eps 1e-12; cambrian_arch.py:1664) */
+int tdc_l2_normalize(void* x, int ld, int rows, int cols, int dtype, void* stream);
+/* SVA core (tdc/vision_sampler.py:215-291): per query (frame t, window (i,j)) attend over the 2x2 windows of
+ * n_towers towers: q [T*side*side, ldq]; kv[tower] [T*(side*r)^2, ldkv] with K at col 0 and V at col `dim`;
+ * mask [T*side*side, n_towers*r*r] uint8; out [T*side*side, ldo].  heads x head_dim = dim. */
+typedef struct {
+    const void* q; int ldq;
+    const void* kv[2]; int ldkv;
+    const unsigned char* mask;
+    void* out; int ldo;
+    int T, side, r, n_towers, dim, heads, dtype;
+} tdc_sva_attn_desc;
+int tdc_sva_attention(const tdc_sva_attn_desc* d, void* stream);
+/* Q-Former embeddings (tdc/Qformer.py:78-108): h[f, s] = LN(s < K ? query[qsrc[f], s] : word[ids[s-K]] + pos[s-K])
+ * -> h32 [F*(K+Lt), ld] fp32 and h16 */
+typedef struct {
+    const void* query; int ldq; const int* qsrc;
+    const float* word; const float* pos; int ldw; const int* ids; int Lt;
+    const float* gamma; const float* beta; float eps;
+    float* h32; void* h16; int ld;
+    int F, K, cols, dtype;
+} tdc_qembed_desc;
+int tdc_qformer_embed(const tdc_qembed_desc* d, void* stream);
+
+/* library / device info */
+const char* tdc_version(void);
+int tdc_device_info(int* cu_count, size_t* hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

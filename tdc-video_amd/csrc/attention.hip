@@ -1,0 +1,285 @@
+// tdc_attention: flash-style softmax(Q K^T * scale) V for the ViT towers (S = 729/730, d = 72/64) and the Q-Former
+// self / cross attention (d = 64).  No mask on this path (BERT masks are all-zero).
+//
+// Workgroup = 4 waves; each wave owns QT tiles of 16 query rows (BQ = 64*QT rows per workgroup) of one (batch, head);
+// K/V tiles of 64 keys are staged global -> registers -> LDS (loads for tile t+1 are issued before the MFMAs of tile
+// t, written after the barrier: the "async-STAGE split", T14).
+//  * S^T = K Q^T is computed with the KEY on the MFMA row: lane (g = lane>>4, i = lane&15) holds, for query i, the
+//    scores of keys 16*kt + 4g + reg.  Row max / row sum are then 16 in-register ops + two xor-shuffles (16, 32).
+//  * O^T = V^T P^T: the V^T operand comes from the row-major V tile through ds_read_b64_tr_b16 (hardware transpose
+//    read, T10); the P^T operand is the S^T accumulator converted in place (k-slot (g, j) <-> key
+//    32s + 16(j>>2) + 4g + (j&3), the same permutation on both operands).  The output accumulator has the query on
+//    the lane (same as the statistics: no cross-lane traffic for the rescale) and 4 consecutive head-dim columns in
+//    its 4 registers (8-byte stores).
+//  * K tile rows are XOR-swizzled in 16-byte chunks (chunk ^ (row & (NCH-1))), V rows padded to 160 B: both read
+//    patterns are bank-conflict free for d = 64/72.
+#include "common.h"
+#include "../../include/tdc_hip.h"
+#include <stdio.h>
+
+namespace {
+
+struct AttnArgs {
+    const void *q, *k, *v; void* o;
+    long long q_bs, k_bs, v_bs, o_bs;
+    int q_rs, k_rs, v_rs, o_rs;
+    int heads, d, sq, sk;
+    float scale_log2;
+    int vec_ok;
+};
+
+constexpr int KT = 64;  // keys per tile
+
+// ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-col block of 16-bit elements is returned column-major
+// (lane 4q+p supplies the address of row q, cols 4p..4p+3; lane i receives column i, row q in element q).
+template <class T> __device__ __forceinline__ typename VecOf<T>::v4 tr_read(const T* p) {
+    s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+    return __builtin_bit_cast(typename VecOf<T>::v4, r);
+}
+
+// DK: padded head dim for the QK^T contraction (32/64/96); NDV: number of 16-wide output column tiles; QT: q tiles/wave
+template <class T, int DK, int NDV, int QT>
+__global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
+    typedef typename VecOf<T>::v8 v8;
+    typedef typename VecOf<T>::v4 v4;
+    constexpr int NCH = DK / 8;                                 // real 16-B chunks per K row
+    constexpr int NCHP = (NCH <= 4) ? 4 : (NCH <= 8 ? 8 : 16);  // chunks per row incl. padding (power of 2)
+    constexpr int KROW = NCHP * 8;                              // K row stride in elements
+    constexpr int VCH = NDV * 2;                                // 16-B chunks per V row
+    constexpr int VROW = 80;                                    // V row stride in elements (160 B)
+    static_assert(NDV * 16 <= VROW, "V row");
+    constexpr int KSTEPS = DK / 32;
+    __shared__ __attribute__((aligned(16))) T Ks[KT * KROW];
+    __shared__ __attribute__((aligned(16))) T Vs[KT * VROW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
+    const int d = p.d;
+    const T* Q = (const T*)p.q + b * p.q_bs + h * d;
+    const T* K = (const T*)p.k + b * p.k_bs + h * d;
+    const T* V = (const T*)p.v + b * p.v_bs + h * d;
+    T* O = (T*)p.o + b * p.o_bs + h * d;
+
+    auto load8 = [&](const T* row, int c0) -> v8 {  // 8 elements row[c0..c0+7], zero beyond d
+        v8 r;
+        if (p.vec_ok) {
+            if (c0 < d) r = *(const v8*)(row + c0);
+            else
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r[e] = (T)0.f;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = (c0 + e < d) ? row[c0 + e] : (T)0.f;
+        }
+        return r;
+    };
+
+    // ---- Q fragments (B operand: lane holds Q[q0 + li][32 ks + 8 g .. +7]); scores are scaled in fp32 afterwards
+    v8 qf[QT][KSTEPS];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        int qr = q0 + t * 16 + li;
+        if (qr > p.sq - 1) qr = p.sq - 1;
+        const T* row = Q + (long long)qr * p.q_rs;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            qf[t][ks] = load8(row, ks * 32 + g * 8);
+        }
+    }
+
+    // ---- staging: K tile = 64 x NCH chunks, V tile = 64 x VCH chunks, 256 threads
+    constexpr int KLD = (KT * NCH + 255) / 256, VLD = (KT * VCH + 255) / 256;
+    v8 kreg[KLD], vreg[VLD];
+    auto issue_loads = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < KLD; ++i) {
+            int idx = tid + i * 256;
+            int key = idx / NCH, c = idx - key * NCH;
+            int kr = kv0 + key; if (kr > p.sk - 1) kr = p.sk - 1;
+            if (idx < KT * NCH) kreg[i] = load8(K + (long long)kr * p.k_rs, c * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < VLD; ++i) {
+            int idx = tid + i * 256;
+            int key = idx / VCH, c = idx - key * VCH;
+            int kr = kv0 + key; if (kr > p.sk - 1) kr = p.sk - 1;
+            if (idx < KT * VCH) vreg[i] = load8(V + (long long)kr * p.v_rs, c * 8);
+        }
+    };
+    auto write_lds = [&]() {
+#pragma unroll
+        for (int i = 0; i < KLD; ++i) {
+            int idx = tid + i * 256;
+            int key = idx / NCH, c = idx - key * NCH;
+            if (idx < KT * NCH) *(v8*)(Ks + key * KROW + ((c ^ (key & (NCHP - 1))) << 3)) = kreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < VLD; ++i) {
+            int idx = tid + i * 256;
+            int key = idx / VCH, c = idx - key * VCH;
+            if (idx < KT * VCH) *(v8*)(Vs + key * VROW + (c << 3)) = vreg[i];
+        }
+    };
+
+    f32x4 o_acc[QT][NDV];
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        m_run[t] = -INFINITY;
+        l_run[t] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < NDV; ++dt) o_acc[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int ntiles = (p.sk + KT - 1) / KT;
+    issue_loads(0);
+    for (int tile = 0; tile < ntiles; ++tile) {
+        __syncthreads();  // every wave finished reading the previous tile
+        write_lds();
+        __syncthreads();
+        if (tile + 1 < ntiles) issue_loads((tile + 1) * KT);
+        const int kv0 = tile * KT;
+
+        // ---- S^T = K Q^T : s[t][kt] holds keys kv0 + 16 kt + 4 g + reg for query li
+        f32x4 s[QT][4];
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) s[t][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const int key = kt * 16 + li;
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                const int c = ks * 4 + g;
+                v8 kf = *(const v8*)(Ks + key * KROW + ((c ^ (key & (NCHP - 1))) << 3));
+#pragma unroll
+                for (int t = 0; t < QT; ++t) s[t][kt] = mfma16(kf, qf[t][ks], s[t][kt]);
+            }
+        }
+        // ---- online softmax (base 2)
+        v8 pf[QT][2];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int key = kv0 + kt * 16 + g * 4 + r;
+                    float x = (key < p.sk) ? s[t][kt][r] * p.scale_log2 : -INFINITY;
+                    s[t][kt][r] = x;
+                    mx = fmaxf(mx, x);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run[t], mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
+            m_run[t] = m_new;
+            float rs = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float e = __builtin_amdgcn_exp2f(s[t][kt][r] - m_new);
+                    rs += e;
+                    pf[t][kt >> 1][(kt & 1) * 4 + r] = (T)e;
+                }
+            l_run[t] = l_run[t] * alpha + rs;
+#pragma unroll
+            for (int dt = 0; dt < NDV; ++dt) o_acc[t][dt] *= alpha;
+        }
+        // ---- O^T += V^T P^T : A operand = V^T via transposed LDS reads
+#pragma unroll
+        for (int dt = 0; dt < NDV; ++dt) {
+#pragma unroll
+            for (int sstep = 0; sstep < 2; ++sstep) {
+                // lane 4q+pp of group g supplies the address of row (key) 32 s + 4 g + q (+16), cols 16 dt + 4 pp ..
+                const int qq = li >> 2, pp = li & 3;
+                const T* a0 = Vs + (sstep * 32 + g * 4 + qq) * VROW + dt * 16 + pp * 4;
+                v4 lo = tr_read<T>(a0);
+                v4 hi = tr_read<T>(a0 + 16 * VROW);
+                v8 vf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+#pragma unroll
+                for (int t = 0; t < QT; ++t) o_acc[t][dt] = mfma16(vf, pf[t][sstep], o_acc[t][dt]);
+            }
+        }
+    }
+
+    // ---- finalise: lane holds O[q = q0 + 16 t + li][16 dt + 4 g + reg]
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        float l = l_run[t];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        const int qr = q0 + t * 16 + li;
+        if (qr >= p.sq) continue;
+        T* orow = O + (long long)qr * p.o_rs;
+#pragma unroll
+        for (int dt = 0; dt < NDV; ++dt) {
+            const int c = dt * 16 + g * 4;
+            if (p.vec_ok && c + 3 < d) {
+                v4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (T)(o_acc[t][dt][e] * inv);
+                *(v4*)(orow + c) = o;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < d) orow[c + e] = (T)(o_acc[t][dt][e] * inv);
+            }
+        }
+    }
+}
+
+template <class T, int DK, int NDV>
+int launch_qt(const AttnArgs& a, int batch, hipStream_t st) {
+    if (a.sq > 64) {
+        dim3 grid((a.sq + 127) / 128, a.heads, batch);
+        hipLaunchKernelGGL((attn_kernel<T, DK, NDV, 2>), grid, dim3(256), 0, st, a);
+    } else {
+        dim3 grid((a.sq + 63) / 64, a.heads, batch);
+        hipLaunchKernelGGL((attn_kernel<T, DK, NDV, 1>), grid, dim3(256), 0, st, a);
+    }
+    return (int)hipGetLastError();
+}
+
+template <class T>
+int launch(const AttnArgs& a, int batch, hipStream_t st) {
+    const int d = a.d;
+    if (d <= 16) return launch_qt<T, 32, 1>(a, batch, st);
+    if (d <= 32) return launch_qt<T, 32, 2>(a, batch, st);
+    if (d <= 64) return launch_qt<T, 64, 4>(a, batch, st);
+    if (d <= 80) return launch_qt<T, 96, 5>(a, batch, st);
+    return TDC_E_BADARG;
+}
+
+}  // namespace
+
+extern "C" int tdc_attention(const tdc_attn_desc* d, void* stream) {
+    if (!d || !d->q || !d->k || !d->v || !d->o) return TDC_E_BADARG;
+    if (d->batch <= 0 || d->heads <= 0 || d->sq <= 0 || d->sk <= 0 || d->head_dim <= 0 || d->head_dim > 80) {
+        fprintf(stderr, "[tdc_hip] tdc_attention: bad shape (head_dim=%d)\n", d->head_dim);
+        return TDC_E_BADARG;
+    }
+    if (d->heads > 65535 || d->batch > 65535) return TDC_E_BADARG;
+    AttnArgs a;
+    a.q = d->q; a.k = d->k; a.v = d->v; a.o = d->o;
+    a.q_bs = d->q_bs; a.k_bs = d->k_bs; a.v_bs = d->v_bs; a.o_bs = d->o_bs;
+    a.q_rs = d->q_rs; a.k_rs = d->k_rs; a.v_rs = d->v_rs; a.o_rs = d->o_rs;
+    a.heads = d->heads; a.d = d->head_dim; a.sq = d->sq; a.sk = d->sk;
+    a.scale_log2 = d->scale * 1.4426950408889634f;
+    auto al = [](const void* p, int bytes) { return ((uintptr_t)p % bytes) == 0; };
+    a.vec_ok = (d->head_dim % 8 == 0) && (d->q_rs % 8 == 0) && (d->k_rs % 8 == 0) && (d->v_rs % 8 == 0) &&
+               (d->o_rs % 4 == 0) && (d->q_bs % 8 == 0) && (d->k_bs % 8 == 0) && (d->v_bs % 8 == 0) &&
+               (d->o_bs % 4 == 0) && al(d->q, 16) && al(d->k, 16) && al(d->v, 16) && al(d->o, 8);
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == TDC_F16) return launch<f16>(a, d->batch, st);
+    if (d->dtype == TDC_BF16) return launch<bf16>(a, d->batch, st);
+    return TDC_E_BADARG;
+}

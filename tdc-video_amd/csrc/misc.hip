@@ -1,0 +1,326 @@
+// Data-movement and small reduction kernels of the path (HBM-bound or tiny): im2col, cls rows, token-grid resample,
+// adjacent-frame cosine similarity, token mean / adaptive pooling, row gather (unpad+newline, token emission) and the
+// SVA 2x2-window cross-attention core.
+#include "common.h"
+#include "../../include/tdc_hip.h"
+#include <stdio.h>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ im2col
+// patches[(b*gh+gy)*gw+gx][c*p*p + ky*p + kx] = px[b][c][gy*p+ky][gx*p+kx]; one workgroup per patch row (b,gy):
+// reads are contiguous along W, writes contiguous along the patch vector.
+template <class T>
+__global__ __launch_bounds__(256) void im2col_kernel(const void* px, int px_f32, T* out, int ldp, int H, int W,
+                                                     int patch, int gh, int gw) {
+    const int b = blockIdx.y, gy = blockIdx.x;
+    const int kdim = 3 * patch * patch;
+    const long long img = (long long)b * 3 * H * W;
+    for (int idx = threadIdx.x; idx < gw * ldp; idx += 256) {
+        int gx = idx / ldp, k = idx - gx * ldp;
+        float v = 0.f;
+        if (k < kdim) {
+            int c = k / (patch * patch), rem = k - c * patch * patch;
+            int ky = rem / patch, kx = rem - ky * patch;
+            long long src = img + ((long long)c * H + gy * patch + ky) * W + gx * patch + kx;
+            v = px_f32 ? ((const float*)px)[src] : (float)((const T*)px)[src];
+        }
+        out[((long long)(b * gh + gy) * gw + gx) * ldp + k] = (T)v;
+    }
+}
+
+__global__ void set_rows_kernel(float* x, int ld, int S, int row, const float* vec) {
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < ld; c += blockDim.x) x[((long long)b * S + row) * ld + c] = vec[c];
+}
+
+// ------------------------------------------------------------------------------------------------ resample
+template <class T>
+__global__ __launch_bounds__(256) void resample_kernel(const void* x, int x_f32, int ldx, int tok_off, int n_in,
+                                                       T* y, int ldy, int n_out, const int* i0, const int* i1,
+                                                       const float* fr, int cols) {
+    // F.interpolate(bilinear) is separable; torch evaluates w00*a + w01*b + w10*c + w11*d per output pixel
+    const int b = blockIdx.y, o = blockIdx.x;
+    const int oy = o / n_out, ox = o - oy * n_out;
+    const int y0 = i0[oy], y1 = i1[oy], x0 = i0[ox], x1 = i1[ox];
+    const float fy = fr[oy], fx = fr[ox];
+    const long long base = (long long)b * (tok_off + n_in * n_in) + tok_off;
+    const long long r00 = (base + y0 * n_in + x0) * ldx, r01 = (base + y0 * n_in + x1) * ldx;
+    const long long r10 = (base + y1 * n_in + x0) * ldx, r11 = (base + y1 * n_in + x1) * ldx;
+    T* out = y + ((long long)b * n_out * n_out + o) * ldy;
+    for (int c = threadIdx.x; c < ldy; c += 256) {
+        float v = 0.f;
+        if (c < cols) {
+            float a, bb, cc, d;
+            if (x_f32) {
+                const float* p = (const float*)x;
+                a = p[r00 + c]; bb = p[r01 + c]; cc = p[r10 + c]; d = p[r11 + c];
+            } else {
+                const T* p = (const T*)x;
+                a = (float)p[r00 + c]; bb = (float)p[r01 + c]; cc = (float)p[r10 + c]; d = (float)p[r11 + c];
+            }
+            v = (1.f - fy) * ((1.f - fx) * a + fx * bb) + fy * ((1.f - fx) * cc + fx * d);
+        }
+        out[c] = (T)v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ cos-sim
+// pass 1: partial sums of <f_t, f_t> and <f_t, f_{t+1}> (fp32, fixed reduction order => deterministic ranking);
+// grid (chunks, T).  pass 2: combine.
+constexpr int CS_CHUNKS = 32;
+template <class T>
+__global__ __launch_bounds__(256) void cossim_partial(const T* f, long long n, int Tn, float* part) {
+    typedef typename VecOf<T>::v8 v8;
+    const int t = blockIdx.y, ch = blockIdx.x;
+    const long long per = ((n / 8 + CS_CHUNKS - 1) / CS_CHUNKS) * 8;
+    const long long lo = ch * per, hi = (lo + per < n) ? lo + per : n;
+    const T* a = f + (long long)t * n;
+    const T* b = f + (long long)(t + 1 < Tn ? t + 1 : t) * n;
+    float saa = 0.f, sab = 0.f;
+    for (long long i = lo + threadIdx.x * 8; i < hi; i += 256 * 8) {
+        v8 va = *(const v8*)(a + i), vb = *(const v8*)(b + i);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = (float)va[e], y = (float)vb[e];
+            saa += x * x;
+            sab += x * y;
+        }
+    }
+    __shared__ float red[2][4];
+    saa = wave_sum(saa); sab = wave_sum(sab);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = saa; red[1][w] = sab; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[((long long)t * CS_CHUNKS + ch) * 2 + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        part[((long long)t * CS_CHUNKS + ch) * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+__global__ void cossim_final(const float* part, int Tn, float* sims) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Tn - 1) return;
+    float aa = 0.f, ab = 0.f, bb = 0.f;
+    for (int c = 0; c < CS_CHUNKS; ++c) {
+        aa += part[((long long)t * CS_CHUNKS + c) * 2];
+        ab += part[((long long)t * CS_CHUNKS + c) * 2 + 1];
+        bb += part[((long long)(t + 1) * CS_CHUNKS + c) * 2];
+    }
+    // F.cosine_similarity: x.y / max(|x| |y|, eps) with eps = 1e-8
+    sims[t] = ab / fmaxf(sqrtf(aa) * sqrtf(bb), 1e-8f);
+}
+
+// ------------------------------------------------------------------------------------------------ pooling
+template <class T>
+__global__ __launch_bounds__(256) void token_mean_kernel(const T* x, int P, int ld, T* y) {
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < ld; c += 256) {
+        float s = 0.f;
+        for (int t = 0; t < P; ++t) s += (float)x[((long long)b * P + t) * ld + c];
+        y[(long long)b * ld + c] = (T)(s / (float)P);
+    }
+}
+template <class T>
+__global__ __launch_bounds__(256) void adaptive_pool_kernel(const T* x, int N, int ld, T* y, int K,
+                                                            const int* src_row) {
+    const int b = blockIdx.y, k = blockIdx.x;
+    const int s = (k * N) / K, e = ((k + 1) * N + K - 1) / K;
+    const long long xb = (long long)(src_row ? src_row[b] : b) * N;
+    for (int c = threadIdx.x; c < ld; c += 256) {
+        float acc = 0.f;
+        for (int t = s; t < e; ++t) acc += (float)x[(xb + t) * ld + c];
+        y[((long long)b * K + k) * ld + c] = (T)(acc / (float)(e - s));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ gather
+template <class T>
+__global__ __launch_bounds__(256) void gather_kernel(tdc_gather_tables t, const int* src, T* out, int ldo, int n,
+                                                     int cols) {
+    const int i = blockIdx.x;
+    const int k = src[2 * i], r = src[2 * i + 1];
+    const T* row = (const T*)t.base[k] + (long long)r * t.ld[k];
+    T* o = out + (long long)i * ldo;
+    typedef typename VecOf<T>::v8 v8;
+    const bool vec = ((cols & 7) == 0) && ((t.ld[k] & 7) == 0) && ((ldo & 7) == 0) &&
+                     (((uintptr_t)t.base[k] & 15) == 0) && (((uintptr_t)out & 15) == 0);
+    if (vec) {
+        for (int c = threadIdx.x * 8; c < cols; c += 256 * 8) *(v8*)(o + c) = *(const v8*)(row + c);
+    } else {
+        for (int c = threadIdx.x; c < cols; c += 256) o[c] = row[c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ SVA core
+// one wave per (query, head-group): q_len = 1, kv = n_towers * r * r <= 8 keys.  Each lane owns dim/64 channels;
+// head h covers channels [h*hd, (h+1)*hd): per-head dot products are reduced inside the lanes that share a head.
+struct SvaArgs {
+    const void* q; int ldq;
+    const void* kv[2]; int ldkv;
+    const unsigned char* mask;
+    void* out; int ldo;
+    int T, side, r, n_towers, dim, heads;
+};
+template <class T>
+__global__ __launch_bounds__(256) void sva_kernel(SvaArgs p) {
+    // thread <-> channel c (strided by 256) ; per-head reduction through LDS (heads <= 64, kv <= 8)
+    __shared__ float sc[8][64];  // [key][head]
+    const int qi = blockIdx.x;   // query index = (t*side + i)*side + j
+    const int nq = p.side * p.side;
+    const int t = qi / nq, w = qi - t * nq;
+    const int wi = w / p.side, wj = w - wi * p.side;
+    const int n = p.side * p.r;
+    const int hd = p.dim / p.heads;
+    const int nkv = p.n_towers * p.r * p.r;
+    for (int i = threadIdx.x; i < 8 * 64; i += 256) ((float*)sc)[i] = 0.f;
+    __syncthreads();
+    const T* q = (const T*)p.q + (long long)qi * p.ldq;
+    // scores: partial dot per thread then atomicAdd in LDS per head
+    const bool wave_per_head = (hd % 64) == 0;  // a wave's 64 channels then lie in one head: deterministic reduce
+    for (int c0 = 0; c0 < p.dim; c0 += 256) {
+        const int c = c0 + threadIdx.x;
+        const bool live = c < p.dim;
+        const float qc = live ? (float)q[c] : 0.f;
+        const int h = (live ? c : p.dim - 1) / hd;
+        int key = 0;
+        for (int tw = 0; tw < p.n_towers; ++tw)
+            for (int a = 0; a < p.r; ++a)
+                for (int b = 0; b < p.r; ++b, ++key) {
+                    long long tok = (long long)t * n * n + (wi * p.r + a) * n + (wj * p.r + b);
+                    const T* kr = (const T*)p.kv[tw] + tok * p.ldkv;
+                    float prod = live ? qc * (float)kr[c] : 0.f;
+                    if (wave_per_head) {
+                        prod = wave_sum(prod);
+                        if ((threadIdx.x & 63) == 0 && live) atomicAdd(&sc[key][h], prod);  // hd == 64: one wave per head
+                    } else if (live) {
+                        atomicAdd(&sc[key][h], prod);
+                    }
+                }
+    }
+    __syncthreads();
+    // softmax per head over the kv keys (masked), one thread per head
+    if (threadIdx.x < p.heads) {
+        const int h = threadIdx.x;
+        const float scale = rsqrtf((float)hd);
+        float mx = -INFINITY;
+        float s[8];
+        for (int k = 0; k < nkv; ++k) {
+            bool ok = p.mask[(long long)qi * nkv + k] != 0;
+            s[k] = ok ? sc[k][h] * scale : -INFINITY;
+            mx = fmaxf(mx, s[k]);
+        }
+        float sum = 0.f;
+        for (int k = 0; k < nkv; ++k) { s[k] = __expf(s[k] - mx); sum += s[k]; }
+        for (int k = 0; k < nkv; ++k) sc[k][h] = s[k] / sum;
+    }
+    __syncthreads();
+    T* o = (T*)p.out + (long long)qi * p.ldo;
+    for (int c = threadIdx.x; c < p.dim; c += 256) {
+        const int h = c / hd;
+        float acc = 0.f;
+        int key = 0;
+        for (int tw = 0; tw < p.n_towers; ++tw)
+            for (int a = 0; a < p.r; ++a)
+                for (int b = 0; b < p.r; ++b, ++key) {
+                    long long tok = (long long)t * n * n + (wi * p.r + a) * n + (wj * p.r + b);
+                    const T* vr = (const T*)p.kv[tw] + tok * p.ldkv + p.dim;
+                    acc += sc[key][h] * (float)vr[c];
+                }
+        o[c] = (T)acc;
+    }
+}
+
+}  // namespace
+
+#define DISPATCH(dtype, CALL)                       \
+    if ((dtype) == TDC_F16) { typedef f16 TT; CALL; }    \
+    else if ((dtype) == TDC_BF16) { typedef bf16 TT; CALL; } \
+    else return TDC_E_BADARG;
+
+extern "C" int tdc_im2col(const void* px, int px_f32, void* patches, int ldp, int B, int H, int W, int patch,
+                          int dtype, void* stream) {
+    if (!px || !patches || B <= 0 || patch <= 0 || ldp < 3 * patch * patch) return TDC_E_BADARG;
+    const int gh = H / patch, gw = W / patch;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH(dtype, hipLaunchKernelGGL(im2col_kernel<TT>, dim3(gh, B), dim3(256), 0, st, px, px_f32, (TT*)patches,
+                                       ldp, H, W, patch, gh, gw));
+    return (int)hipGetLastError();
+}
+
+extern "C" int tdc_set_rows(float* x32, int ld, int B, int S, int row, const float* vec, void* stream) {
+    if (!x32 || !vec || B <= 0) return TDC_E_BADARG;
+    hipLaunchKernelGGL(set_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x32, ld, S, row, vec);
+    return (int)hipGetLastError();
+}
+
+extern "C" int tdc_resample_tokens(const void* x, int x_f32, int ldx, int tok_off, int n_in, void* y, int ldy,
+                                   int n_out, const int* idx0, const int* idx1, const float* frac, int B, int cols,
+                                   int dtype, void* stream) {
+    if (!x || !y || !idx0 || !idx1 || !frac || B <= 0) return TDC_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH(dtype, hipLaunchKernelGGL(resample_kernel<TT>, dim3(n_out * n_out, B), dim3(256), 0, st, x, x_f32, ldx,
+                                       tok_off, n_in, (TT*)y, ldy, n_out, idx0, idx1, frac, cols));
+    return (int)hipGetLastError();
+}
+
+extern "C" int tdc_frame_cossim(const void* f, long long n, int T, float* sims, float* scratch, int dtype,
+                                void* stream) {
+    if (!f || !sims || !scratch || T < 2 || n <= 0 || (n % 8) != 0) return TDC_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH(dtype, hipLaunchKernelGGL(cossim_partial<TT>, dim3(CS_CHUNKS, T), dim3(256), 0, st, (const TT*)f, n, T,
+                                       scratch));
+    hipLaunchKernelGGL(cossim_final, dim3((T + 255) / 256), dim3(256), 0, st, scratch, T, sims);
+    return (int)hipGetLastError();
+}
+extern "C" size_t tdc_frame_cossim_scratch_floats(int T) { return (size_t)T * CS_CHUNKS * 2; }
+
+extern "C" int tdc_token_mean(const void* x, int P, int ld, void* y, int B, int dtype, void* stream) {
+    if (!x || !y || B <= 0 || P <= 0) return TDC_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH(dtype, hipLaunchKernelGGL(token_mean_kernel<TT>, dim3(B), dim3(256), 0, st, (const TT*)x, P, ld, (TT*)y));
+    return (int)hipGetLastError();
+}
+
+extern "C" int tdc_adaptive_pool_tokens(const void* x, int N, int ld, void* y, int K, int B, const int* src_row,
+                                        int dtype, void* stream) {
+    if (!x || !y || B <= 0 || N <= 0 || K <= 0) return TDC_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH(dtype, hipLaunchKernelGGL(adaptive_pool_kernel<TT>, dim3(K, B), dim3(256), 0, st, (const TT*)x, N, ld,
+                                       (TT*)y, K, src_row));
+    return (int)hipGetLastError();
+}
+
+extern "C" int tdc_gather_rows(const tdc_gather_tables* t, const int* src, void* out, int ldo, int n, int cols,
+                               int dtype, void* stream) {
+    if (!t || !src || !out || n <= 0) return TDC_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH(dtype, hipLaunchKernelGGL(gather_kernel<TT>, dim3(n), dim3(256), 0, st, *t, src, (TT*)out, ldo, n, cols));
+    return (int)hipGetLastError();
+}
+
+extern "C" int tdc_sva_attention(const tdc_sva_attn_desc* d, void* stream) {
+    if (!d || !d->q || !d->kv[0] || !d->mask || !d->out) return TDC_E_BADARG;
+    if (d->n_towers < 1 || d->n_towers > 2 || d->n_towers * d->r * d->r > 8 || d->heads > 64 ||
+        d->dim % d->heads != 0)
+        return TDC_E_BADARG;
+    SvaArgs a;
+    a.q = d->q; a.ldq = d->ldq; a.kv[0] = d->kv[0]; a.kv[1] = d->kv[1]; a.ldkv = d->ldkv; a.mask = d->mask;
+    a.out = d->out; a.ldo = d->ldo; a.T = d->T; a.side = d->side; a.r = d->r; a.n_towers = d->n_towers;
+    a.dim = d->dim; a.heads = d->heads;
+    hipStream_t st = (hipStream_t)stream;
+    const int nq = d->T * d->side * d->side;
+    DISPATCH(d->dtype, hipLaunchKernelGGL(sva_kernel<TT>, dim3(nq), dim3(256), 0, st, a));
+    return (int)hipGetLastError();
+}
+
+extern "C" const char* tdc_version(void) { return "tdc_hip 0.1 (gfx950)"; }
+
+extern "C" int tdc_device_info(int* cu_count, size_t* hbm_bytes) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    HIP_CHECK_RET(hipGetDevice(&dev));
+    HIP_CHECK_RET(hipGetDeviceProperties(&prop, dev));
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    return 0;
+}

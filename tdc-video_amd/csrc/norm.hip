@@ -1,0 +1,218 @@
+// LayerNorm / L2-normalise / Q-Former embedding+LN: HBM-bound row kernels, one wave per row, fp32 statistics.
+#include "common.h"
+#include "../../include/tdc_hip.h"
+#include <stdio.h>
+
+namespace {
+
+// One wave (64 lanes) per row; a row of up to 64*MAXV columns is kept in registers (MAXV elements per lane,
+// strided by 64 so that consecutive lanes touch consecutive addresses).
+constexpr int MAXV = 64;  // supports up to 4096 columns
+
+struct LnArgs {
+    const void* x; int ldx; int x_f32;
+    void* y16; int ldy16;
+    float* y32; int ldy32;
+    const float* gamma; const float* beta; float eps;
+    const float* add; int ldadd; int add_period; int add_mode; int add_side;
+    int rows, cols, pad_cols;
+};
+
+template <class T, int NV>
+__global__ __launch_bounds__(256) void ln_kernel(LnArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    float v[NV];
+    const float* addrow = nullptr;
+    if (p.add) {
+        int t = row % p.add_period;
+        if (p.add_mode == 1) {
+            int y = t / p.add_side, x = t - y * p.add_side;
+            t = (y & 1) * 2 + (x & 1);
+        }
+        addrow = p.add + (long long)t * p.ldadd;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int c = lane + i * 64;
+        float a = 0.f;
+        if (c < p.cols) {
+            a = p.x_f32 ? ((const float*)p.x)[(long long)row * p.ldx + c]
+                        : (float)((const T*)p.x)[(long long)row * p.ldx + c];
+            if (addrow) a += addrow[c];
+        }
+        v[i] = a;
+        s += a;
+    }
+    s = wave_sum(s);
+    const float mean = s / (float)p.cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int c = lane + i * 64;
+        float d = (c < p.cols) ? v[i] - mean : 0.f;
+        q += d * d;
+    }
+    q = wave_sum(q);
+    const float rstd = rsqrtf(q / (float)p.cols + p.eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int c = lane + i * 64;
+        if (c < p.pad_cols) {
+            float o = 0.f;
+            if (c < p.cols) o = (v[i] - mean) * rstd * p.gamma[c] + p.beta[c];
+            if (p.y16) ((T*)p.y16)[(long long)row * p.ldy16 + c] = (T)o;
+            if (p.y32) p.y32[(long long)row * p.ldy32 + c] = o;
+        }
+    }
+}
+
+template <class T>
+int launch_ln(const LnArgs& a, hipStream_t st) {
+    const int nv = (a.pad_cols + 63) / 64;
+    dim3 grid((a.rows + 3) / 4), block(256);
+    if (nv <= 1) hipLaunchKernelGGL((ln_kernel<T, 1>), grid, block, 0, st, a);
+    else if (nv <= 2) hipLaunchKernelGGL((ln_kernel<T, 2>), grid, block, 0, st, a);
+    else if (nv <= 12) hipLaunchKernelGGL((ln_kernel<T, 12>), grid, block, 0, st, a);
+    else if (nv <= 16) hipLaunchKernelGGL((ln_kernel<T, 16>), grid, block, 0, st, a);
+    else if (nv <= 18) hipLaunchKernelGGL((ln_kernel<T, 18>), grid, block, 0, st, a);
+    else if (nv <= 24) hipLaunchKernelGGL((ln_kernel<T, 24>), grid, block, 0, st, a);
+    else if (nv <= MAXV) hipLaunchKernelGGL((ln_kernel<T, MAXV>), grid, block, 0, st, a);
+    else return TDC_E_BADARG;
+    return (int)hipGetLastError();
+}
+
+// ---- L2 normalise in place --------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void l2n_kernel(T* x, int ld, int rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    T* r = x + (long long)row * ld;
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) { float a = (float)r[c]; s += a * a; }
+    s = wave_sum(s);
+    const float inv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+    for (int c = lane; c < cols; c += 64) r[c] = (T)((float)r[c] * inv);
+}
+
+// ---- Q-Former embeddings + LayerNorm -------------------------------------------------------------------------
+struct QeArgs {
+    const void* query; int ldq; const int* qsrc;
+    const float* word; const float* pos; int ldw; const int* ids; int Lt;
+    const float* gamma; const float* beta; float eps;
+    float* h32; void* h16; int ld;
+    int F, K, cols;
+};
+
+template <class T, int NV>
+__global__ __launch_bounds__(256) void qembed_kernel(QeArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int S = p.K + p.Lt;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.F * S) return;
+    const int f = row / S, s = row - f * S;
+    float v[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int c = lane + i * 64;
+        float a = 0.f;
+        if (c < p.cols) {
+            if (s < p.K) {
+                a = (float)((const T*)p.query)[((long long)p.qsrc[f] * p.K + s) * p.ldq + c];
+            } else {
+                int t = s - p.K;
+                a = p.word[(long long)p.ids[t] * p.ldw + c] + p.pos[(long long)t * p.ldw + c];
+            }
+        }
+        v[i] = a;
+        sum += a;
+    }
+    sum = wave_sum(sum);
+    const float mean = sum / (float)p.cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int c = lane + i * 64;
+        float d = (c < p.cols) ? v[i] - mean : 0.f;
+        q += d * d;
+    }
+    q = wave_sum(q);
+    const float rstd = rsqrtf(q / (float)p.cols + p.eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int c = lane + i * 64;
+        if (c < p.ld) {
+            float o = (c < p.cols) ? (v[i] - mean) * rstd * p.gamma[c] + p.beta[c] : 0.f;
+            p.h32[(long long)row * p.ld + c] = o;
+            ((T*)p.h16)[(long long)row * p.ld + c] = (T)o;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int tdc_layernorm(const tdc_ln_desc* d, void* stream) {
+    if (!d || !d->x || d->rows <= 0 || d->cols <= 0 || (!d->y16 && !d->y32)) return TDC_E_BADARG;
+    LnArgs a;
+    a.x = d->x; a.ldx = d->ldx; a.x_f32 = d->x_f32;
+    a.y16 = d->y16; a.ldy16 = d->ldy16; a.y32 = d->y32; a.ldy32 = d->ldy32;
+    a.gamma = d->gamma; a.beta = d->beta; a.eps = d->eps;
+    a.add = d->add; a.ldadd = d->ldadd; a.add_period = d->add_period > 0 ? d->add_period : 1;
+    a.add_mode = d->add_mode;
+    a.add_side = 1;
+    if (d->add_mode == 1) {
+        int s = 1;
+        while (s * s < a.add_period) ++s;
+        a.add_side = s;
+    }
+    a.rows = d->rows; a.cols = d->cols;
+    a.pad_cols = (d->cols + 63) / 64 * 64;
+    int ldmin = a.pad_cols;
+    if ((d->y16 && d->ldy16 < ldmin) || (d->y32 && d->ldy32 < ldmin)) {
+        // outputs narrower than the padded width: only write the real columns
+        a.pad_cols = d->cols;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == TDC_F16) return launch_ln<f16>(a, st);
+    if (d->dtype == TDC_BF16) return launch_ln<bf16>(a, st);
+    return TDC_E_BADARG;
+}
+
+extern "C" int tdc_l2_normalize(void* x, int ld, int rows, int cols, int dtype, void* stream) {
+    if (!x || rows <= 0 || cols <= 0) return TDC_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((rows + 3) / 4), block(256);
+    if (dtype == TDC_F16) hipLaunchKernelGGL(l2n_kernel<f16>, grid, block, 0, st, (f16*)x, ld, rows, cols);
+    else if (dtype == TDC_BF16) hipLaunchKernelGGL(l2n_kernel<bf16>, grid, block, 0, st, (bf16*)x, ld, rows, cols);
+    else return TDC_E_BADARG;
+    return (int)hipGetLastError();
+}
+
+extern "C" int tdc_qformer_embed(const tdc_qembed_desc* d, void* stream) {
+    if (!d || !d->query || !d->h32 || !d->h16 || d->F <= 0 || d->K <= 0) return TDC_E_BADARG;
+    if (d->Lt > 0 && (!d->word || !d->pos || !d->ids)) return TDC_E_BADARG;
+    QeArgs a;
+    a.query = d->query; a.ldq = d->ldq; a.qsrc = d->qsrc;
+    a.word = d->word; a.pos = d->pos; a.ldw = d->ldw; a.ids = d->ids; a.Lt = d->Lt;
+    a.gamma = d->gamma; a.beta = d->beta; a.eps = d->eps;
+    a.h32 = d->h32; a.h16 = d->h16; a.ld = d->ld;
+    a.F = d->F; a.K = d->K; a.cols = d->cols;
+    const int nv = (d->ld + 63) / 64;
+    const int rows = d->F * (d->K + d->Lt);
+    dim3 grid((rows + 3) / 4), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define QE(T)                                                                                   \
+    if (nv <= 2) hipLaunchKernelGGL((qembed_kernel<T, 2>), grid, block, 0, st, a);              \
+    else if (nv <= 12) hipLaunchKernelGGL((qembed_kernel<T, 12>), grid, block, 0, st, a);       \
+    else if (nv <= 16) hipLaunchKernelGGL((qembed_kernel<T, 16>), grid, block, 0, st, a);       \
+    else return TDC_E_BADARG;
+    if (d->dtype == TDC_F16) { QE(f16) }
+    else if (d->dtype == TDC_BF16) { QE(bf16) }
+    else return TDC_E_BADARG;
+#undef QE
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,110 @@
+"""ctypes binding of libtdc_hip.so (C ABI in include/tdc_hip.h).  No CPU fallback: every entry point raises if the
+library cannot be loaded, and compute calls raise on a non-zero return code."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libtdc_hip.so")
+
+F16, BF16 = 0, 1
+ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_SWIGLU = 0, 1, 2, 3
+
+
+class RowMap(C.Structure):
+    _fields_ = [("seg", C.c_int), ("stride", C.c_int), ("off", C.c_int), ("inner", C.c_int)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int), ("W", C.c_void_p), ("ldw", C.c_int),
+                ("C", C.c_void_p), ("ldc", C.c_int), ("bias", C.c_void_p), ("res", C.c_void_p), ("ldres", C.c_int),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("dtype", C.c_int), ("out_f32", C.c_int), ("res_f32", C.c_int), ("act", C.c_int),
+                ("a_map", RowMap), ("c_map", RowMap), ("r_map", RowMap)]
+
+
+class LnDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("ldx", C.c_int), ("x_f32", C.c_int),
+                ("y16", C.c_void_p), ("ldy16", C.c_int), ("y32", C.c_void_p), ("ldy32", C.c_int),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float),
+                ("add", C.c_void_p), ("ldadd", C.c_int), ("add_period", C.c_int), ("add_mode", C.c_int),
+                ("rows", C.c_int), ("cols", C.c_int), ("dtype", C.c_int)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p),
+                ("q_bs", C.c_longlong), ("k_bs", C.c_longlong), ("v_bs", C.c_longlong), ("o_bs", C.c_longlong),
+                ("q_rs", C.c_int), ("k_rs", C.c_int), ("v_rs", C.c_int), ("o_rs", C.c_int),
+                ("batch", C.c_int), ("heads", C.c_int), ("head_dim", C.c_int), ("sq", C.c_int), ("sk", C.c_int),
+                ("scale", C.c_float), ("dtype", C.c_int)]
+
+
+class GatherTables(C.Structure):
+    _fields_ = [("base", C.c_void_p * 4), ("ld", C.c_int * 4)]
+
+
+class SvaAttnDesc(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("ldq", C.c_int), ("kv", C.c_void_p * 2), ("ldkv", C.c_int),
+                ("mask", C.c_void_p), ("out", C.c_void_p), ("ldo", C.c_int),
+                ("T", C.c_int), ("side", C.c_int), ("r", C.c_int), ("n_towers", C.c_int), ("dim", C.c_int),
+                ("heads", C.c_int), ("dtype", C.c_int)]
+
+
+class QEmbedDesc(C.Structure):
+    _fields_ = [("query", C.c_void_p), ("ldq", C.c_int), ("qsrc", C.c_void_p),
+                ("word", C.c_void_p), ("pos", C.c_void_p), ("ldw", C.c_int), ("ids", C.c_void_p), ("Lt", C.c_int),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float),
+                ("h32", C.c_void_p), ("h16", C.c_void_p), ("ld", C.c_int),
+                ("F", C.c_int), ("K", C.c_int), ("cols", C.c_int), ("dtype", C.c_int)]
+
+
+# name -> (restype, argtypes); every symbol include/tdc_hip.h declares
+SIGNATURES = {
+    "tdc_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
+    "tdc_layernorm": (C.c_int, [C.POINTER(LnDesc), C.c_void_p]),
+    "tdc_attention": (C.c_int, [C.POINTER(AttnDesc), C.c_void_p]),
+    "tdc_im2col": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                             C.c_void_p]),
+    "tdc_set_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "tdc_resample_tokens": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "tdc_frame_cossim": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "tdc_frame_cossim_scratch_floats": (C.c_size_t, [C.c_int]),
+    "tdc_token_mean": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "tdc_adaptive_pool_tokens": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                           C.c_int, C.c_void_p]),
+    "tdc_gather_rows": (C.c_int, [C.POINTER(GatherTables), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, C.c_void_p]),
+    "tdc_l2_normalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "tdc_sva_attention": (C.c_int, [C.POINTER(SvaAttnDesc), C.c_void_p]),
+    "tdc_qformer_embed": (C.c_int, [C.POINTER(QEmbedDesc), C.c_void_p]),
+    "tdc_version": (C.c_char_p, []),
+    "tdc_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
+}
+
+_lib = None
+
+
+class TdcHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libtdc_hip.so (built in-tree by build.py).  Raises if missing: there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TdcHipError("libtdc_hip.so not found at %s: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(the product path has no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise TdcHipError("%s failed with code %d" % (what, rc))

@@ -1,0 +1,306 @@
+"""torch-tensor wrappers over the C ABI (include/tdc_hip.h).  torch is used for device memory and streams only; every
+computation below runs in libtdc_hip.so.  Shapes are validated on the host before a launch (a faulting kernel can
+take the whole GPU node down)."""
+import ctypes as C
+import math
+
+import torch
+
+from . import lib as L
+
+
+def _dt(t):
+    if t.dtype == torch.float16:
+        return L.F16
+    if t.dtype == torch.bfloat16:
+        return L.BF16
+    raise TypeError("16-bit tensor expected, got %s" % t.dtype)
+
+
+def _dtcode(dtype):
+    return L.F16 if dtype == torch.float16 else L.BF16
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _chk2d(t, name):
+    assert t.is_cuda and t.dim() == 2 and t.stride(1) == 1, "%s must be a 2-D row-major CUDA tensor" % name
+
+
+def pad64(n):
+    return (n + 63) // 64 * 64
+
+
+def _map(m):
+    if m is None:
+        return L.RowMap(0, 0, 0, 0)
+    return L.RowMap(*m)
+
+
+def _map_max(m, M):
+    """largest row index a row map produces for m in [0, M)."""
+    if m is None:
+        return M - 1
+    seg, stride, off, inner = m
+
+    def f(i):
+        return (i // seg) * stride + off + (i % seg) * inner
+    cand = [M - 1, min(seg - 1, M - 1)]
+    if (M // seg) * seg - 1 >= 0:
+        cand.append((M // seg) * seg - 1)
+    return max(f(i) for i in cand)
+
+
+def gemm(a, w, bias=None, act=L.ACT_NONE, res=None, out=None, out_f32=False, M=None, a_map=None, c_map=None,
+         r_map=None, out_rows=None):
+    """out[c_map(m)] = act(a[a_map(m)] @ w.T + bias) + res[r_map(m)].  a [Ra, lda], w [N, K] (both 16-bit)."""
+    _chk2d(a, "a"); _chk2d(w, "w")
+    N, K = w.shape
+    assert a.dtype == w.dtype and K % 64 == 0 and a.shape[1] >= K, (a.shape, w.shape)
+    if M is None:
+        M = a.shape[0]
+    assert _map_max(a_map, M) < a.shape[0], "a_map out of range"
+    n_out = N // 2 if act == L.ACT_SWIGLU else N
+    if out is None:
+        rows = out_rows if out_rows is not None else M
+        out = torch.empty(rows, n_out, device=a.device, dtype=torch.float32 if out_f32 else a.dtype)
+    _chk2d(out, "out")
+    assert out.shape[1] >= n_out and _map_max(c_map, M) < out.shape[0], "out too small"
+    assert (out.dtype == torch.float32) == bool(out_f32)
+    d = L.GemmDesc()
+    d.A, d.lda = a.data_ptr(), a.stride(0)
+    d.W, d.ldw = w.data_ptr(), w.stride(0)
+    d.C, d.ldc = out.data_ptr(), out.stride(0)
+    d.bias = bias.data_ptr() if bias is not None else None
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() >= N and bias.is_contiguous()
+    if res is not None:
+        _chk2d(res, "res")
+        assert res.shape[1] >= N and _map_max(r_map, M) < res.shape[0], "res too small"
+        d.res, d.ldres = res.data_ptr(), res.stride(0)
+        d.res_f32 = 1 if res.dtype == torch.float32 else 0
+        if not d.res_f32:
+            assert res.dtype == a.dtype
+    d.M, d.N, d.K = M, N, K
+    d.dtype, d.out_f32, d.act = _dt(a), int(out_f32), act
+    d.a_map, d.c_map, d.r_map = _map(a_map), _map(c_map), _map(r_map)
+    L.check(L.load().tdc_gemm(C.byref(d), _stream()), "tdc_gemm")
+    return out
+
+
+def layernorm(x, gamma, beta, eps, cols, dtype, y16=None, y32=None, add=None, add_period=0, add_mode=0,
+              want16=True, want32=False, rows=None):
+    """LayerNorm over the first `cols` columns of x [rows, ld] (fp32 or 16-bit) -> (y16, y32)."""
+    _chk2d(x, "x")
+    rows = x.shape[0] if rows is None else rows
+    ld = pad64(cols)
+    if want16 and y16 is None:
+        y16 = torch.empty(rows, ld, device=x.device, dtype=dtype)
+    if want32 and y32 is None:
+        y32 = torch.empty(rows, ld, device=x.device, dtype=torch.float32)
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() >= cols
+    assert x.shape[1] >= cols and rows <= x.shape[0]
+    d = L.LnDesc()
+    d.x, d.ldx, d.x_f32 = x.data_ptr(), x.stride(0), int(x.dtype == torch.float32)
+    if y16 is not None:
+        assert y16.shape[0] >= rows and y16.shape[1] >= cols and y16.dtype == dtype
+        d.y16, d.ldy16 = y16.data_ptr(), y16.stride(0)
+    if y32 is not None:
+        assert y32.shape[0] >= rows and y32.shape[1] >= cols and y32.dtype == torch.float32
+        d.y32, d.ldy32 = y32.data_ptr(), y32.stride(0)
+    d.gamma, d.beta, d.eps = gamma.data_ptr(), beta.data_ptr(), eps
+    if add is not None:
+        assert add.dtype == torch.float32 and add.dim() == 2 and add.shape[1] >= cols
+        d.add, d.ldadd, d.add_period, d.add_mode = add.data_ptr(), add.stride(0), add_period, add_mode
+        assert add.shape[0] >= (4 if add_mode == 1 else add_period)
+    d.rows, d.cols, d.dtype = rows, cols, _dtcode(dtype)
+    L.check(L.load().tdc_layernorm(C.byref(d), _stream()), "tdc_layernorm")
+    return y16, y32
+
+
+def attention(q, k, v, out, batch, heads, head_dim, sq, sk, scale, q_bs, k_bs, v_bs, o_bs):
+    """q/k/v/out: 2-D views [tokens, ld] whose element (b, s, h, c) sits at base + b*bs + s*stride(0) + h*head_dim + c.
+    Tensors may be column-offset views of a fused QKV buffer."""
+    for t in (q, k, v, out):
+        assert t.is_cuda and t.dim() == 2 and t.stride(1) == 1
+    assert q.dtype == k.dtype == v.dtype == out.dtype
+    assert heads * head_dim <= q.shape[1] and heads * head_dim <= out.shape[1]
+
+    def last(t, bs, s):
+        return (batch - 1) * bs + (s - 1) * t.stride(0) + heads * head_dim
+    for t, bs, s in ((q, q_bs, sq), (k, k_bs, sk), (v, v_bs, sk), (out, o_bs, sq)):
+        span = (t.shape[0] - 1) * t.stride(0) + t.shape[1]
+        assert last(t, bs, s) <= span, "attention view out of range"
+    d = L.AttnDesc()
+    d.q, d.k, d.v, d.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    d.q_bs, d.k_bs, d.v_bs, d.o_bs = q_bs, k_bs, v_bs, o_bs
+    d.q_rs, d.k_rs, d.v_rs, d.o_rs = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+    d.batch, d.heads, d.head_dim, d.sq, d.sk = batch, heads, head_dim, sq, sk
+    d.scale, d.dtype = scale, _dt(q)
+    L.check(L.load().tdc_attention(C.byref(d), _stream()), "tdc_attention")
+    return out
+
+
+def im2col(px, patch, dtype):
+    B, Cc, H, W = px.shape
+    assert Cc == 3 and px.is_contiguous() and px.is_cuda
+    gh, gw = H // patch, W // patch
+    ldp = pad64(3 * patch * patch)
+    out = torch.empty(B * gh * gw, ldp, device=px.device, dtype=dtype)
+    f32 = int(px.dtype == torch.float32)
+    assert f32 or px.dtype == dtype
+    L.check(L.load().tdc_im2col(_ptr(px), f32, _ptr(out), ldp, B, H, W, patch, _dtcode(dtype), _stream()),
+            "tdc_im2col")
+    return out, gh, gw
+
+
+def set_rows(x32, B, S, row, vec):
+    assert x32.dtype == torch.float32 and x32.dim() == 2 and x32.shape[0] >= B * S and vec.numel() >= x32.shape[1]
+    L.check(L.load().tdc_set_rows(_ptr(x32), x32.stride(0), B, S, row, _ptr(vec), _stream()), "tdc_set_rows")
+
+
+def bilinear_tables(n_in, n_out, device):
+    """index / weight tables of F.interpolate(bilinear, align_corners=False) along one axis."""
+    i0, i1, fr = [], [], []
+    scale = n_in / n_out
+    for o in range(n_out):
+        src = max((o + 0.5) * scale - 0.5, 0.0)
+        a = int(math.floor(src))
+        i0.append(a)
+        i1.append(min(a + 1, n_in - 1))
+        fr.append(src - a)
+    return (torch.tensor(i0, dtype=torch.int32, device=device), torch.tensor(i1, dtype=torch.int32, device=device),
+            torch.tensor(fr, dtype=torch.float32, device=device))
+
+
+def resample_tokens(x, B, tok_off, n_in, n_out, cols, dtype, tables):
+    _chk2d(x, "x")
+    assert x.shape[0] >= B * (tok_off + n_in * n_in) and x.shape[1] >= cols
+    ldy = pad64(cols)
+    y = torch.empty(B * n_out * n_out, ldy, device=x.device, dtype=dtype)
+    i0, i1, fr = tables
+    assert i0.numel() == n_out and int(i1.max()) < n_in
+    L.check(L.load().tdc_resample_tokens(_ptr(x), int(x.dtype == torch.float32), x.stride(0), tok_off, n_in, _ptr(y),
+                                         ldy, n_out, _ptr(i0), _ptr(i1), _ptr(fr), B, cols, _dtcode(dtype), _stream()),
+            "tdc_resample_tokens")
+    return y
+
+
+def frame_cossim(f, T, n):
+    """f: 16-bit [T*tokens, ld] viewed as [T, n] -> sims fp32 [T-1]."""
+    assert f.is_cuda and f.is_contiguous() and f.numel() >= T * n and n % 8 == 0 and T >= 2
+    lib = L.load()
+    scratch = torch.empty(lib.tdc_frame_cossim_scratch_floats(T), device=f.device, dtype=torch.float32)
+    sims = torch.empty(T - 1, device=f.device, dtype=torch.float32)
+    L.check(lib.tdc_frame_cossim(_ptr(f), n, T, _ptr(sims), _ptr(scratch), _dt(f), _stream()), "tdc_frame_cossim")
+    return sims
+
+
+def token_mean(x, B, P):
+    _chk2d(x, "x")
+    assert x.shape[0] >= B * P and x.is_contiguous()
+    y = torch.empty(B, x.shape[1], device=x.device, dtype=x.dtype)
+    L.check(L.load().tdc_token_mean(_ptr(x), P, x.stride(0), _ptr(y), B, _dt(x), _stream()), "tdc_token_mean")
+    return y
+
+
+def adaptive_pool_tokens(x, N, K, B, src_row=None):
+    _chk2d(x, "x")
+    assert x.is_contiguous()
+    if src_row is not None:
+        assert src_row.dtype == torch.int32 and src_row.numel() >= B
+        assert (int(src_row.max()) + 1) * N <= x.shape[0]
+    else:
+        assert B * N <= x.shape[0]
+    y = torch.empty(B * K, x.shape[1], device=x.device, dtype=x.dtype)
+    L.check(L.load().tdc_adaptive_pool_tokens(_ptr(x), N, x.stride(0), _ptr(y), K, B, _ptr(src_row), _dt(x),
+                                              _stream()), "tdc_adaptive_pool_tokens")
+    return y
+
+
+def gather_rows(tables, src, n, cols, out=None):
+    """tables: list of <= 4 2-D 16-bit tensors; src int32 [n, 2] (table, row)."""
+    gt = L.GatherTables()
+    dtype = tables[0].dtype
+    rows_ok = []
+    for i, t in enumerate(tables):
+        if t.dim() == 1:
+            t = t.view(1, -1)
+        assert t.is_cuda and t.stride(1) == 1 and t.dtype == dtype and t.shape[1] >= cols
+        gt.base[i] = t.data_ptr()
+        gt.ld[i] = t.stride(0)
+        rows_ok.append(t.shape[0])
+    assert src.dtype == torch.int32 and src.is_contiguous() and src.numel() >= 2 * n
+    s = src.view(-1, 2)[:n]
+    assert int(s[:, 0].max()) < len(tables) and int(s[:, 0].min()) >= 0
+    for i, r in enumerate(rows_ok):
+        sel = s[:, 1][s[:, 0] == i]
+        if sel.numel():
+            assert int(sel.max()) < r and int(sel.min()) >= 0, "gather row out of range"
+    if out is None:
+        out = torch.empty(n, cols, device=src.device, dtype=dtype)
+    assert out.shape[0] >= n and out.shape[1] >= cols and out.stride(1) == 1
+    L.check(L.load().tdc_gather_rows(C.byref(gt), _ptr(src), _ptr(out), out.stride(0), n, cols, _dtcode(dtype),
+                                     _stream()), "tdc_gather_rows")
+    return out
+
+
+def l2_normalize(x, rows, cols):
+    _chk2d(x, "x")
+    assert x.shape[0] >= rows and x.shape[1] >= cols
+    L.check(L.load().tdc_l2_normalize(_ptr(x), x.stride(0), rows, cols, _dt(x), _stream()), "tdc_l2_normalize")
+    return x
+
+
+def sva_attention(q, kv_list, mask, T, side, r, dim, heads, out=None):
+    _chk2d(q, "q")
+    nq = T * side * side
+    n = side * r
+    assert q.shape[0] >= nq and q.shape[1] >= dim
+    d = L.SvaAttnDesc()
+    d.q, d.ldq = q.data_ptr(), q.stride(0)
+    for i, kv in enumerate(kv_list):
+        _chk2d(kv, "kv")
+        assert kv.shape[0] >= T * n * n and kv.shape[1] >= 2 * dim and kv.dtype == q.dtype
+        assert kv.stride(0) == kv_list[0].stride(0)
+        d.kv[i] = kv.data_ptr()
+    d.ldkv = kv_list[0].stride(0)
+    nkv = len(kv_list) * r * r
+    assert mask.dtype == torch.uint8 and mask.is_contiguous() and mask.numel() >= nq * nkv
+    d.mask = mask.data_ptr()
+    if out is None:
+        out = torch.empty(nq, pad64(dim), device=q.device, dtype=q.dtype)
+        if out.shape[1] > dim:
+            out[:, dim:].zero_()
+    d.out, d.ldo = out.data_ptr(), out.stride(0)
+    d.T, d.side, d.r, d.n_towers, d.dim, d.heads, d.dtype = T, side, r, len(kv_list), dim, heads, _dt(q)
+    L.check(L.load().tdc_sva_attention(C.byref(d), _stream()), "tdc_sva_attention")
+    return out
+
+
+def qformer_embed(query, qsrc, word, pos, ids, gamma, beta, eps, F, K, cols, dtype):
+    _chk2d(query, "query")
+    Lt = 0 if ids is None else ids.numel()
+    ld = pad64(cols)
+    rows = F * (K + Lt)
+    h32 = torch.empty(rows, ld, device=query.device, dtype=torch.float32)
+    h16 = torch.empty(rows, ld, device=query.device, dtype=dtype)
+    assert qsrc.dtype == torch.int32 and qsrc.numel() >= F and (int(qsrc.max()) + 1) * K <= query.shape[0]
+    d = L.QEmbedDesc()
+    d.query, d.ldq, d.qsrc = query.data_ptr(), query.stride(0), qsrc.data_ptr()
+    if Lt:
+        assert ids.dtype == torch.int32 and word.dtype == torch.float32 and pos.dtype == torch.float32
+        assert int(ids.max()) < word.shape[0] and Lt <= pos.shape[0] and word.stride(0) == pos.stride(0)
+        d.word, d.pos, d.ldw, d.ids = word.data_ptr(), pos.data_ptr(), word.stride(0), ids.data_ptr()
+    d.Lt = Lt
+    d.gamma, d.beta, d.eps = gamma.data_ptr(), beta.data_ptr(), eps
+    d.h32, d.h16, d.ld = h32.data_ptr(), h16.data_ptr(), ld
+    d.F, d.K, d.cols, d.dtype = F, K, cols, _dtcode(dtype)
+    L.check(L.load().tdc_qformer_embed(C.byref(d), _stream()), "tdc_qformer_embed")
+    return h32, h16

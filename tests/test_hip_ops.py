@@ -1,0 +1,261 @@
+"""GPU parity of every C-ABI primitive against a plain torch fp32 reference of the same op (run with -m gpu)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float16, torch.bfloat16]
+
+
+def tol(dtype):
+    return 2e-3 if dtype == torch.float16 else 1.6e-2
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import tdc_video_amd  # noqa: F401
+    from tdc_video_amd import ops as o
+    assert torch.cuda.is_available()
+    return o
+
+
+def relerr(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item()
+
+
+def test_gemm_integer_layout(ops):
+    """exact small-integer data with an ASYMMETRIC pattern: catches transposed / permuted fragments."""
+    M, N, K = 200, 136, 128
+    a = ((torch.arange(M).view(-1, 1) * 3 + torch.arange(K).view(1, -1)) % 7 - 3).half().cuda()
+    w = ((torch.arange(N).view(-1, 1) * 5 + torch.arange(K).view(1, -1) * 2) % 5 - 2).half().cuda()
+    out = ops.gemm(a, w, out_f32=True)
+    ref = a.float() @ w.float().t()
+    assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,K", [(1, 64, 64), (129, 192, 64), (300, 4352, 1152), (1000, 1152, 4352)])
+def test_gemm_plain(ops, dtype, M, N, K):
+    g = torch.Generator(device="cuda").manual_seed(0)
+    a = torch.randn(M, K, device="cuda", generator=g).to(dtype)
+    w = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).to(dtype)
+    bias = torch.randn(N, device="cuda", generator=g)
+    out = ops.gemm(a, w, bias)
+    ref = a.float() @ w.float().t() + bias
+    assert relerr(out, ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_epilogues(ops, dtype):
+    from tdc_video_amd import lib as L
+    g = torch.Generator(device="cuda").manual_seed(1)
+    M, N, K = 257, 256, 192
+    a = torch.randn(M, K, device="cuda", generator=g).to(dtype)
+    w = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).to(dtype)
+    bias = torch.randn(N, device="cuda", generator=g)
+    lin = a.float() @ w.float().t() + bias
+    assert relerr(ops.gemm(a, w, bias, act=L.ACT_GELU_ERF), F.gelu(lin)) < tol(dtype)
+    assert relerr(ops.gemm(a, w, bias, act=L.ACT_GELU_TANH), F.gelu(lin, approximate="tanh")) < tol(dtype)
+    sw = ops.gemm(a, w, bias, act=L.ACT_SWIGLU)
+    assert sw.shape == (M, N // 2)
+    assert relerr(sw, F.silu(lin[:, 0::2]) * lin[:, 1::2]) < tol(dtype)
+    res32 = torch.randn(M, N, device="cuda", generator=g)
+    o32 = ops.gemm(a, w, bias, res=res32, out_f32=True)
+    assert relerr(o32, lin + res32) < tol(dtype)
+    # in-place on the residual stream (C aliases res)
+    r2 = res32.clone()
+    ops.gemm(a, w, bias, res=r2, out=r2, out_f32=True)
+    assert torch.equal(r2, o32)
+    res16 = res32.to(dtype)
+    assert relerr(ops.gemm(a, w, bias, res=res16), lin + res16.float()) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_row_maps(ops, dtype):
+    g = torch.Generator(device="cuda").manual_seed(2)
+    F_, S, Kq, D, N = 5, 11, 4, 128, 64
+    h = torch.randn(F_ * S, D, device="cuda", generator=g).to(dtype)
+    w = (torch.randn(N, D, device="cuda", generator=g) / math.sqrt(D)).to(dtype)
+    # A rows: first Kq rows of every S-row segment; C rows: rows 1.. of (Kq+1)-row segments; residual: one row / segment
+    perframe = torch.randn(F_, N, device="cuda", generator=g)
+    out = torch.zeros(F_ * (Kq + 1), N, device="cuda", dtype=torch.float32)
+    ops.gemm(h, w, None, res=perframe, out=out, out_f32=True, M=F_ * Kq, a_map=(Kq, S, 0, 1),
+             c_map=(Kq, Kq + 1, 1, 1), r_map=(Kq, 1, 0, 0))
+    hq = h.view(F_, S, D)[:, :Kq].float()
+    ref = hq @ w.float().t() + perframe[:, None, :]
+    got = out.view(F_, Kq + 1, N)
+    assert relerr(got[:, 1:], ref) < tol(dtype)
+    assert torch.count_nonzero(got[:, 0]) == 0
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cols", [48, 64, 768, 1024, 1152, 1536, 3584])
+def test_layernorm(ops, dtype, cols):
+    g = torch.Generator(device="cuda").manual_seed(3)
+    rows, ld = 37, ops.pad64(cols)
+    x = torch.zeros(rows, ld, device="cuda")
+    x[:, :cols] = torch.randn(rows, cols, device="cuda", generator=g) * 3 + 1
+    gamma = torch.randn(cols, device="cuda", generator=g)
+    beta = torch.randn(cols, device="cuda", generator=g)
+    y16, y32 = ops.layernorm(x, gamma, beta, 1e-6, cols, dtype, want32=True)
+    ref = F.layer_norm(x[:, :cols], (cols,), gamma, beta, 1e-6)
+    assert (y32[:, :cols] - ref).abs().max().item() < 2e-5
+    assert relerr(y16[:, :cols], ref) < tol(dtype)
+    assert torch.count_nonzero(y16[:, cols:]) == 0
+    # 16-bit input + additive table (SVA window positions)
+    x16 = x.to(dtype)
+    add = torch.randn(4, cols, device="cuda", generator=g)
+    side = 6
+    y16b, _ = ops.layernorm(x16[:36], gamma, beta, 1e-5, cols, dtype, add=add, add_period=side * side, add_mode=1)
+    t = torch.arange(36, device="cuda")
+    widx = ((t // side) & 1) * 2 + ((t % side) & 1)
+    refb = F.layer_norm(x16[:36, :cols].float() + add[widx], (cols,), gamma, beta, 1e-5)
+    assert relerr(y16b[:, :cols], refb) < tol(dtype)
+
+
+def _attn_ref(q, k, v, scale):
+    return torch.softmax((q.float() @ k.float().transpose(-1, -2)) * scale, -1) @ v.float()
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,H,d,sq,sk", [(2, 3, 64, 200, 200), (1, 2, 72, 729, 729), (2, 4, 64, 730, 730),
+                                         (3, 12, 64, 16, 156), (2, 12, 64, 28, 28), (2, 4, 12, 81, 81),
+                                         (2, 4, 16, 82, 82), (3, 2, 64, 144, 206), (1, 16, 72, 576, 576)])
+def test_attention(ops, dtype, B, H, d, sq, sk):
+    g = torch.Generator(device="cuda").manual_seed(4)
+    D = H * d
+    ldq = ops.pad64(3 * D)
+    # fused-QKV style buffer for self attention, separate buffers otherwise
+    if sq == sk:
+        qkv = torch.randn(B * sq, ldq, device="cuda", generator=g).to(dtype)
+        q, k, v = qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D]
+        qb = kb = sq * ldq
+    else:
+        qbuf = torch.randn(B * sq, ops.pad64(D), device="cuda", generator=g).to(dtype)
+        kvbuf = torch.randn(B * sk, ops.pad64(2 * D), device="cuda", generator=g).to(dtype)
+        q, k, v = qbuf[:, :D], kvbuf[:, :D], kvbuf[:, D:2 * D]
+        qb, kb = sq * qbuf.stride(0), sk * kvbuf.stride(0)
+    out = torch.zeros(B * sq, ops.pad64(D), device="cuda", dtype=dtype)
+    scale = 1.0 / math.sqrt(d)
+    ops.attention(q, k, v, out, B, H, d, sq, sk, scale, qb, kb, kb, sq * out.stride(0))
+    qh = q.reshape(B, sq, H, d).transpose(1, 2)
+    kh = k.reshape(B, sk, H, d).transpose(1, 2)
+    vh = v.reshape(B, sk, H, d).transpose(1, 2)
+    ref = _attn_ref(qh, kh, vh, scale).transpose(1, 2).reshape(B * sq, D)
+    assert relerr(out[:, :D], ref) < 2 * tol(dtype)
+    assert torch.count_nonzero(out[:, D:]) == 0
+
+
+def test_attention_integer_layout(ops):
+    """V = one-hot-ish integers, uniform scores: catches a wrong key permutation / transposed-read mapping."""
+    B, H, d, S = 1, 1, 64, 64
+    q = torch.zeros(S, d, device="cuda", dtype=torch.float16)
+    k = torch.zeros(S, d, device="cuda", dtype=torch.float16)
+    v = ((torch.arange(S).view(-1, 1) * 7 + torch.arange(d).view(1, -1) * 3) % 11).half().cuda()
+    out = torch.zeros(S, d, device="cuda", dtype=torch.float16)
+    ops.attention(q, k, v, out, B, H, d, S, S, 1.0, S * d, S * d, S * d, S * d)
+    ref = v.float().mean(0, keepdim=True).expand(S, d)
+    assert (out.float() - ref).abs().max().item() < 1e-2
+    # peaked attention: query i selects key (S-1-i) exactly
+    q = torch.zeros(S, d, device="cuda", dtype=torch.float16)
+    k = torch.zeros(S, d, device="cuda", dtype=torch.float16)
+    for i in range(S):
+        q[i, i % d] = 30.0
+        k[S - 1 - i, i % d] = 30.0
+    # make keys unique per query: add a second coordinate
+    out2 = torch.zeros(S, d, device="cuda", dtype=torch.float16)
+    ops.attention(q, k, v, out2, B, H, d, S, S, 1.0, S * d, S * d, S * d, S * d)
+    ref2 = _attn_ref(q[None, None], k[None, None], v[None, None], 1.0)[0, 0]
+    assert (out2.float() - ref2).abs().max().item() < 2e-2
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_small_kernels(ops, dtype):
+    g = torch.Generator(device="cuda").manual_seed(5)
+    # im2col == unfold
+    px = torch.randn(2, 3, 42, 56, device="cuda", generator=g)
+    pat, gh, gw = ops.im2col(px, 14, dtype)
+    ref = F.unfold(px, 14, stride=14).transpose(1, 2).reshape(2 * gh * gw, -1)
+    assert relerr(pat[:, :588], ref) < tol(dtype) and torch.count_nonzero(pat[:, 588:]) == 0
+    # resample == F.interpolate bilinear (with cls offset)
+    B, n_in, n_out, D = 2, 9, 8, 64
+    x = torch.randn(B * (1 + n_in * n_in), D, device="cuda", generator=g)
+    y = ops.resample_tokens(x, B, 1, n_in, n_out, D, dtype, ops.bilinear_tables(n_in, n_out, "cuda"))
+    grid = x.view(B, 1 + n_in * n_in, D)[:, 1:].reshape(B, n_in, n_in, D).permute(0, 3, 1, 2)
+    refi = F.interpolate(grid, size=(n_out, n_out), mode="bilinear", align_corners=False)
+    assert relerr(y[:, :D], refi.permute(0, 2, 3, 1).reshape(-1, D)) < tol(dtype)
+    # cosine similarity of adjacent frames
+    T, n = 7, 64 * 40
+    f = torch.randn(T, n, device="cuda", generator=g).to(dtype)
+    sims = ops.frame_cossim(f, T, n)
+    refs = F.cosine_similarity(f[:-1].float(), f[1:].float(), dim=1)
+    assert (sims - refs).abs().max().item() < 1e-5
+    # token mean / adaptive pool / gather / l2
+    x16 = torch.randn(3 * 20, 64, device="cuda", generator=g).to(dtype)
+    assert relerr(ops.token_mean(x16, 3, 20), x16.view(3, 20, 64).float().mean(1)) < tol(dtype)
+    src_row = torch.tensor([2, 0], dtype=torch.int32, device="cuda")
+    pooled = ops.adaptive_pool_tokens(x16, 20, 6, 2, src_row)
+    refp = F.adaptive_avg_pool1d(x16.view(3, 20, 64)[[2, 0]].float().transpose(1, 2), 6).transpose(1, 2)
+    assert relerr(pooled, refp.reshape(12, 64)) < tol(dtype)
+    vec = torch.randn(64, device="cuda", generator=g).to(dtype)
+    src = torch.tensor([[0, 5], [1, 0], [0, 59], [1, 0]], dtype=torch.int32, device="cuda")
+    got = ops.gather_rows([x16, vec], src, 4, 64)
+    assert torch.equal(got, torch.stack([x16[5], vec, x16[59], vec]))
+    z = x16.clone()
+    ops.l2_normalize(z, 60, 64)
+    assert relerr(z, F.normalize(x16.float(), dim=-1)) < tol(dtype)
+    # set_rows
+    r32 = torch.zeros(2 * 5, 64, device="cuda")
+    v32 = torch.randn(64, device="cuda", generator=g)
+    ops.set_rows(r32, 2, 5, 0, v32)
+    assert torch.equal(r32[0], v32) and torch.equal(r32[5], v32) and torch.count_nonzero(r32[1:5]) == 0
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("dim,heads", [(64, 16), (1024, 16)])
+def test_sva_attention(ops, dtype, dim, heads):
+    g = torch.Generator(device="cuda").manual_seed(6)
+    T, side, r = 2, 3, 2
+    n = side * r
+    nq = T * side * side
+    q = torch.randn(nq, dim, device="cuda", generator=g).to(dtype)
+    kv = [torch.randn(T * n * n, 2 * dim, device="cuda", generator=g).to(dtype) for _ in range(2)]
+    mask = (torch.rand(nq, 8, device="cuda", generator=g) > 0.3)
+    mask[:, 0] = True
+    out = ops.sva_attention(q, kv, mask.to(torch.uint8).contiguous(), T, side, r, dim, heads)
+    # reference: gather the 2x2 windows
+    def win(x):
+        return x.view(T, side, r, side, r, -1).permute(0, 1, 3, 2, 4, 5).reshape(nq, r * r, -1)
+    K = torch.cat([win(t[:, :dim].float()) for t in kv], 1)
+    V = torch.cat([win(t[:, dim:].float()) for t in kv], 1)
+    hd = dim // heads
+    qh = q.float().view(nq, heads, 1, hd)
+    kh = K.view(nq, 8, heads, hd).transpose(1, 2)
+    vh = V.view(nq, 8, heads, hd).transpose(1, 2)
+    s = (qh @ kh.transpose(-1, -2)) / math.sqrt(hd)
+    s = s.masked_fill(~mask[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(s, -1) @ vh).reshape(nq, dim)
+    assert relerr(out[:, :dim], ref) < 2 * tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_qformer_embed(ops, dtype):
+    g = torch.Generator(device="cuda").manual_seed(7)
+    D, K, Lt, F_, nchunk = 768, 16, 5, 6, 2
+    query = torch.randn(nchunk * K, D, device="cuda", generator=g).to(dtype)
+    qsrc = torch.tensor([0, 0, 0, 1, 1, 1], dtype=torch.int32, device="cuda")
+    word = torch.randn(50, D, device="cuda", generator=g)
+    pos = torch.randn(32, D, device="cuda", generator=g)
+    ids = torch.tensor([3, 7, 7, 49, 0], dtype=torch.int32, device="cuda")
+    gamma = torch.randn(D, device="cuda", generator=g)
+    beta = torch.randn(D, device="cuda", generator=g)
+    h32, h16 = ops.qformer_embed(query, qsrc, word, pos, ids, gamma, beta, 1e-12, F_, K, D, dtype)
+    te = word[ids.long()] + pos[:Lt]
+    rows = torch.cat([query.view(nchunk, K, D)[qsrc.long()].float(), te[None].expand(F_, -1, -1)], 1)
+    ref = F.layer_norm(rows, (D,), gamma, beta, 1e-12).reshape(-1, D)
+    assert (h32[:, :D] - ref).abs().max().item() < 1e-4
+    assert relerr(h16[:, :D], ref) < tol(dtype)
