@@ -64,6 +64,7 @@ typedef struct {
     const float* gamma; const float* beta; float eps;
     const float* add; int ldadd; int add_period; int add_mode;
     int rows, cols, dtype;
+    tdc_rowmap x_map, y_map; /* row r reads x[x_map(r)] and writes y*[y_map(r)] (identity when seg == 0) */
 } tdc_ln_desc;
 int tdc_layernorm(const tdc_ln_desc* d, void* stream);
 
@@ -99,10 +100,11 @@ int tdc_frame_cossim(const void* f, long long n, int T, float* sims, float* scra
 size_t tdc_frame_cossim_scratch_floats(int T);
 /* mean over the token axis: x [B, P, ld] 16-bit -> y [B, ld] 16-bit (global context, cambrian_arch.py:1009) */
 int tdc_token_mean(const void* x, int P, int ld, void* y, int B, int dtype, void* stream);
-/* adaptive_avg_pool1d over the token axis: x [B, N, ld] -> y [B, K, ld] (cambrian_arch.py:1633-1637); rows of x for
- * batch b start at x + src_row[b]*N*ld when src_row != NULL */
-int tdc_adaptive_pool_tokens(const void* x, int N, int ld, void* y, int K, int B, const int* src_row, int dtype,
-                             void* stream);
+/* adaptive_avg_pool1d over the token axis: y[b, k] = mean of x rows [floor(kN/K), ceil((k+1)N/K)) of frame
+ * src_row[b] (b when NULL); frame f starts at row f*frame_rows (frame_rows >= N: extra rows, e.g. audio tokens, are
+ * not pooled - the key frame is pooled BEFORE the audio concat, cambrian_arch.py:1609,1633-1637) */
+int tdc_adaptive_pool_tokens(const void* x, int N, int frame_rows, int ld, void* y, int K, int B,
+                             const int* src_row, int dtype, void* stream);
 /* out[i, :cols] = table_k[row] where (k,row) = src[2i], src[2i+1]; tables: up to 4 16-bit matrices with their ld.
  * Used for unpad+newline (cambrian_arch.py:1195-1293) and token emission (:1668-1709). */
 typedef struct { const void* base[4]; int ld[4]; } tdc_gather_tables;

@@ -121,11 +121,11 @@ __global__ __launch_bounds__(256) void token_mean_kernel(const T* x, int P, int 
     }
 }
 template <class T>
-__global__ __launch_bounds__(256) void adaptive_pool_kernel(const T* x, int N, int ld, T* y, int K,
+__global__ __launch_bounds__(256) void adaptive_pool_kernel(const T* x, int N, int frame_rows, int ld, T* y, int K,
                                                             const int* src_row) {
     const int b = blockIdx.y, k = blockIdx.x;
     const int s = (k * N) / K, e = ((k + 1) * N + K - 1) / K;
-    const long long xb = (long long)(src_row ? src_row[b] : b) * N;
+    const long long xb = (long long)(src_row ? src_row[b] : b) * frame_rows;
     for (int c = threadIdx.x; c < ld; c += 256) {
         float acc = 0.f;
         for (int t = s; t < e; ++t) acc += (float)x[(xb + t) * ld + c];
@@ -281,12 +281,12 @@ extern "C" int tdc_token_mean(const void* x, int P, int ld, void* y, int B, int 
     return (int)hipGetLastError();
 }
 
-extern "C" int tdc_adaptive_pool_tokens(const void* x, int N, int ld, void* y, int K, int B, const int* src_row,
-                                        int dtype, void* stream) {
-    if (!x || !y || B <= 0 || N <= 0 || K <= 0) return TDC_E_BADARG;
+extern "C" int tdc_adaptive_pool_tokens(const void* x, int N, int frame_rows, int ld, void* y, int K, int B,
+                                        const int* src_row, int dtype, void* stream) {
+    if (!x || !y || B <= 0 || N <= 0 || K <= 0 || frame_rows < N) return TDC_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH(dtype, hipLaunchKernelGGL(adaptive_pool_kernel<TT>, dim3(K, B), dim3(256), 0, st, (const TT*)x, N, ld,
-                                       (TT*)y, K, src_row));
+    DISPATCH(dtype, hipLaunchKernelGGL(adaptive_pool_kernel<TT>, dim3(K, B), dim3(256), 0, st, (const TT*)x, N,
+                                       frame_rows, ld, (TT*)y, K, src_row));
     return (int)hipGetLastError();
 }
 

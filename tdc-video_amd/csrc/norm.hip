@@ -16,6 +16,7 @@ struct LnArgs {
     const float* gamma; const float* beta; float eps;
     const float* add; int ldadd; int add_period; int add_mode; int add_side;
     int rows, cols, pad_cols;
+    RowMap xm, ym;
 };
 
 template <class T, int NV>
@@ -23,6 +24,7 @@ __global__ __launch_bounds__(256) void ln_kernel(LnArgs p) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.rows) return;
+    const long long xrow = p.xm(row), yrow = p.ym(row);
     float v[NV];
     const float* addrow = nullptr;
     if (p.add) {
@@ -39,8 +41,7 @@ __global__ __launch_bounds__(256) void ln_kernel(LnArgs p) {
         int c = lane + i * 64;
         float a = 0.f;
         if (c < p.cols) {
-            a = p.x_f32 ? ((const float*)p.x)[(long long)row * p.ldx + c]
-                        : (float)((const T*)p.x)[(long long)row * p.ldx + c];
+            a = p.x_f32 ? ((const float*)p.x)[xrow * p.ldx + c] : (float)((const T*)p.x)[xrow * p.ldx + c];
             if (addrow) a += addrow[c];
         }
         v[i] = a;
@@ -63,8 +64,8 @@ __global__ __launch_bounds__(256) void ln_kernel(LnArgs p) {
         if (c < p.pad_cols) {
             float o = 0.f;
             if (c < p.cols) o = (v[i] - mean) * rstd * p.gamma[c] + p.beta[c];
-            if (p.y16) ((T*)p.y16)[(long long)row * p.ldy16 + c] = (T)o;
-            if (p.y32) p.y32[(long long)row * p.ldy32 + c] = o;
+            if (p.y16) ((T*)p.y16)[yrow * p.ldy16 + c] = (T)o;
+            if (p.y32) p.y32[yrow * p.ldy32 + c] = o;
         }
     }
 }
@@ -170,6 +171,8 @@ extern "C" int tdc_layernorm(const tdc_ln_desc* d, void* stream) {
         a.add_side = s;
     }
     a.rows = d->rows; a.cols = d->cols;
+    a.xm = {d->x_map.seg, d->x_map.stride, d->x_map.off, d->x_map.inner};
+    a.ym = {d->y_map.seg, d->y_map.stride, d->y_map.off, d->y_map.inner};
     a.pad_cols = (d->cols + 63) / 64 * 64;
     int ldmin = a.pad_cols;
     if ((d->y16 && d->ldy16 < ldmin) || (d->y32 && d->ldy32 < ldmin)) {

@@ -27,7 +27,8 @@ class LnDesc(C.Structure):
                 ("y16", C.c_void_p), ("ldy16", C.c_int), ("y32", C.c_void_p), ("ldy32", C.c_int),
                 ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float),
                 ("add", C.c_void_p), ("ldadd", C.c_int), ("add_period", C.c_int), ("add_mode", C.c_int),
-                ("rows", C.c_int), ("cols", C.c_int), ("dtype", C.c_int)]
+                ("rows", C.c_int), ("cols", C.c_int), ("dtype", C.c_int),
+                ("x_map", RowMap), ("y_map", RowMap)]
 
 
 class AttnDesc(C.Structure):
@@ -70,8 +71,8 @@ SIGNATURES = {
     "tdc_frame_cossim": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "tdc_frame_cossim_scratch_floats": (C.c_size_t, [C.c_int]),
     "tdc_token_mean": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
-    "tdc_adaptive_pool_tokens": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
-                                           C.c_int, C.c_void_p]),
+    "tdc_adaptive_pool_tokens": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                           C.c_void_p, C.c_int, C.c_void_p]),
     "tdc_gather_rows": (C.c_int, [C.POINTER(GatherTables), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.c_void_p]),
     "tdc_l2_normalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -95,7 +95,7 @@ def gemm(a, w, bias=None, act=L.ACT_NONE, res=None, out=None, out_f32=False, M=N
 
 
 def layernorm(x, gamma, beta, eps, cols, dtype, y16=None, y32=None, add=None, add_period=0, add_mode=0,
-              want16=True, want32=False, rows=None):
+              want16=True, want32=False, rows=None, x_map=None, y_map=None):
     """LayerNorm over the first `cols` columns of x [rows, ld] (fp32 or 16-bit) -> (y16, y32)."""
     _chk2d(x, "x")
     rows = x.shape[0] if rows is None else rows
@@ -105,14 +105,16 @@ def layernorm(x, gamma, beta, eps, cols, dtype, y16=None, y32=None, add=None, ad
     if want32 and y32 is None:
         y32 = torch.empty(rows, ld, device=x.device, dtype=torch.float32)
     assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() >= cols
-    assert x.shape[1] >= cols and rows <= x.shape[0]
+    assert x.shape[1] >= cols and _map_max(x_map, rows) < x.shape[0]
+    ymax = _map_max(y_map, rows)
     d = L.LnDesc()
+    d.x_map, d.y_map = _map(x_map), _map(y_map)
     d.x, d.ldx, d.x_f32 = x.data_ptr(), x.stride(0), int(x.dtype == torch.float32)
     if y16 is not None:
-        assert y16.shape[0] >= rows and y16.shape[1] >= cols and y16.dtype == dtype
+        assert y16.shape[0] > ymax and y16.shape[1] >= cols and y16.dtype == dtype
         d.y16, d.ldy16 = y16.data_ptr(), y16.stride(0)
     if y32 is not None:
-        assert y32.shape[0] >= rows and y32.shape[1] >= cols and y32.dtype == torch.float32
+        assert y32.shape[0] > ymax and y32.shape[1] >= cols and y32.dtype == torch.float32
         d.y32, d.ldy32 = y32.data_ptr(), y32.stride(0)
     d.gamma, d.beta, d.eps = gamma.data_ptr(), beta.data_ptr(), eps
     if add is not None:
@@ -210,17 +212,19 @@ def token_mean(x, B, P):
     return y
 
 
-def adaptive_pool_tokens(x, N, K, B, src_row=None):
+def adaptive_pool_tokens(x, N, K, B, src_row=None, frame_rows=None):
     _chk2d(x, "x")
     assert x.is_contiguous()
+    frame_rows = N if frame_rows is None else frame_rows
+    assert frame_rows >= N
     if src_row is not None:
         assert src_row.dtype == torch.int32 and src_row.numel() >= B
-        assert (int(src_row.max()) + 1) * N <= x.shape[0]
+        assert int(src_row.max()) * frame_rows + N <= x.shape[0] and int(src_row.min()) >= 0
     else:
-        assert B * N <= x.shape[0]
+        assert (B - 1) * frame_rows + N <= x.shape[0]
     y = torch.empty(B * K, x.shape[1], device=x.device, dtype=x.dtype)
-    L.check(L.load().tdc_adaptive_pool_tokens(_ptr(x), N, x.stride(0), _ptr(y), K, B, _ptr(src_row), _dt(x),
-                                              _stream()), "tdc_adaptive_pool_tokens")
+    L.check(L.load().tdc_adaptive_pool_tokens(_ptr(x), N, frame_rows, x.stride(0), _ptr(y), K, B, _ptr(src_row),
+                                              _dt(x), _stream()), "tdc_adaptive_pool_tokens")
     return y
 
 

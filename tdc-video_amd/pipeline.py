@@ -1,0 +1,321 @@
+"""VideoEncoder: the hot path (stages S0-S10) as a sequence of libtdc_hip.so launches.
+
+Python only sequences kernels and owns the buffers (torch tensors as device memory); every FLOP runs in the HIP
+library.  Stage methods mirror the reference's stages so the parity tests can compare stage by stage:
+  tower()        a2-a4   tdc/multimodal_encoder/{siglip,dino}_encoder.py + HF ViTs
+  frame_sims()   a5      tdc/cambrian_arch.py:832-842
+  connector()    a6-a10  tdc/cambrian_arch.py:1002-1053 (aux projectors, SVA), :1149-1150 (mm_projector), :1176-1293
+  compress()     a11-a19 tdc/cambrian_arch.py:1507-1709 (all chunks of a video batched into ONE Q-Former pass)
+"""
+import math
+
+import torch
+
+from . import lib as L
+from . import ops
+from . import segment as seg
+from . import weights as Wt
+from .weights import pad64
+
+
+class VideoEncoder:
+    def __init__(self, sd, cfg, dtype=torch.float16, device="cuda", siglip_heads=16, dino_heads=24,
+                 qformer_heads=12, tower_batch=64):
+        """sd: reference-named state dict without the leading 'model.'; cfg: dict of reference config keys."""
+        self.cfg = dict(cfg)
+        self.dtype, self.dev = dtype, torch.device(device)
+        self.tower_batch = tower_batch
+        self.qheads = qformer_heads
+        s_sd = Wt._strip(sd, "vision_tower_aux_list.0.vision_tower.")
+        d_sd = Wt._strip(sd, "vision_tower_aux_list.1.vision_tower.")
+        self.towers = {}
+        if s_sd:
+            self.towers["siglip"] = Wt.prep_siglip(s_sd, siglip_heads, dtype, self.dev)
+        if d_sd:
+            self.towers["dino"] = Wt.prep_dino(d_sd, dino_heads, dtype, self.dev)
+        self.c = Wt.prep_connector(sd, cfg, dtype, self.dev)
+        tok = cfg.get("mm_vision_tower_aux_token_len_list", [576, 576])
+        self.out_grid = [int(round(t ** 0.5)) for t in tok]
+        self.side = int(round(cfg.get("query_num_list", [144])[0] ** 0.5))
+        self._tables = {}
+        self.K = cfg.get("context_token_num", 16)
+
+    # ------------------------------------------------------------------------------------------------ towers
+    def _bil(self, n_in, n_out):
+        key = (n_in, n_out)
+        if key not in self._tables:
+            self._tables[key] = ops.bilinear_tables(n_in, n_out, self.dev)
+        return self._tables[key]
+
+    def tower(self, name, px):
+        """px [B,3,H,W] (fp32 or compute dtype) -> features [B*g*g, pad64(D)] 16-bit (g = 24)."""
+        t = self.towers[name]
+        out_grid = self.out_grid[0 if name == "siglip" else 1]
+        outs = []
+        for s in range(0, px.shape[0], self.tower_batch):
+            outs.append(self._tower_batch(t, px[s:s + self.tower_batch].contiguous(), out_grid))
+        return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+
+    def _tower_batch(self, t, px, out_grid):
+        dt, dev = self.dtype, self.dev
+        B = px.shape[0]
+        D, Dp = t.dim, pad64(t.dim)
+        patches, gh, gw = ops.im2col(px, t.patch, dt)
+        assert gh == gw, "square inputs only (reference pads to square, mm_datautils.py:286-314)"
+        P = gh * gw
+        S = P + t.has_cls
+        pos, cls_row = Wt.tower_pos(t, gh, gw, dev)
+        x32 = torch.empty(B * S, Dp, device=dev, dtype=torch.float32)
+        ops.gemm(patches, t.patch_lin.w, t.patch_lin.b, res=pos, r_map=(P, 0, t.has_cls, 1), out=x32, out_f32=True,
+                 c_map=(P, S, t.has_cls, 1))
+        if t.has_cls:
+            ops.set_rows(x32, B, S, 0, cls_row)
+        h16 = torch.empty(B * S, Dp, device=dev, dtype=dt)
+        qkv = torch.empty(B * S, t.layers[0].qkv.w.shape[0], device=dev, dtype=dt) if t.layers else None
+        attn = torch.zeros(B * S, Dp, device=dev, dtype=dt)
+        act = {"gelu_tanh": L.ACT_GELU_TANH, "gelu_erf": L.ACT_GELU_ERF, "swiglu": L.ACT_SWIGLU}[t.act]
+        mlp_w = t.layers[0].fc2.w.shape[1] if t.layers else 0
+        mlp = torch.empty(B * S, mlp_w, device=dev, dtype=dt) if t.layers else None
+        scale = t.head_dim ** -0.5
+        for Lr in t.layers:
+            ops.layernorm(x32, Lr.ln1_g, Lr.ln1_b, t.eps, D, dt, y16=h16)
+            ops.gemm(h16, Lr.qkv.w, Lr.qkv.b, out=qkv)
+            ld = qkv.stride(0)
+            ops.attention(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], attn, B, t.heads, t.head_dim, S, S, scale,
+                          S * ld, S * ld, S * ld, S * attn.stride(0))
+            ops.gemm(attn, Lr.out.w, Lr.out.b, res=x32, out=x32, out_f32=True)
+            ops.layernorm(x32, Lr.ln2_g, Lr.ln2_b, t.eps, D, dt, y16=h16)
+            ops.gemm(h16, Lr.fc1.w, Lr.fc1.b, act=act, out=mlp)
+            ops.gemm(mlp, Lr.fc2.w, Lr.fc2.b, res=x32, out=x32, out_f32=True)
+        src = x32
+        if t.get("final_ln"):
+            ops.layernorm(x32, t.final_ln[0], t.final_ln[1], t.eps, D, dt, y16=h16)
+            src = h16
+        return ops.resample_tokens(src, B, t.has_cls, gh, out_grid, D, dt, self._bil(gh, out_grid))
+
+    # ------------------------------------------------------------------------------------------------ a5
+    def frame_sims(self, dino_feat, T):
+        """adjacent-frame cosine similarity of the DINO features -> python list of T-1 floats (one D2H copy)."""
+        n = dino_feat.shape[0] // T * dino_feat.shape[1]
+        return ops.frame_cossim(dino_feat, T, n).tolist()
+
+    # ------------------------------------------------------------------------------------------------ a6-a10
+    def aux_project(self, feat, i):
+        a = self.c.aux[i]
+        h = ops.gemm(feat, a.fc1.w, a.fc1.b, act=L.ACT_GELU_ERF)
+        y = ops.gemm(h, a.fc2.w, a.fc2.b, out_f32=True)
+        y16, _ = ops.layernorm(y, a.ln_g, a.ln_b, 1e-5, self.c.C, self.dtype)
+        return y16
+
+    def sva(self, aux, T, image_sizes):
+        """aux: two [T*P, pad64(C)] 16-bit tensors -> queries [T*nq, pad64(C)] (vision_sampler_0, 3 layers)."""
+        c, dt, dev = self.c, self.dtype, self.dev
+        C, Cp = c.C, pad64(c.C)
+        side = self.side
+        nq = side * side
+        P = aux[0].shape[0] // T
+        n = int(round(P ** 0.5))
+        r = n // side
+        # masks (host geometry, identical for frames that share an image size)
+        cache = {}
+        rows = []
+        for t in range(T):
+            key = tuple(image_sizes[t])
+            if key not in cache:
+                m0 = seg.window_mask_bytes(side, r, key)
+                cache[key] = [a + b for a, b in zip(m0, m0)]  # both towers share the geometry (same grid)
+            rows.extend(cache[key])
+        mask = torch.tensor(rows, dtype=torch.uint8, device=dev).contiguous()
+        ctx = ops.token_mean(aux[0], T, P)                                    # [T, Cp]
+        q16 = torch.zeros(T * nq, Cp, device=dev, dtype=dt)
+        q16[:, :C] = c.vision_query.to(dt).to(dev)[None, :]
+        M = T * nq
+        for Lr in c.sva:
+            cproj = ops.gemm(ctx, Lr.proj_context.w)                          # [T, Cp]
+            cin = ops.gemm(cproj, Lr.proj_in_c.w, out_f32=True)               # [T, Cp] fp32: per-frame bias
+            qin = ops.gemm(q16, Lr.proj_in_q.w, res=cin, r_map=(nq, 1, 0, 0), out_f32=True)   # proj_in(cat[q, ctx])
+            kvs = []
+            for tw in range(2):
+                xn, _ = ops.layernorm(aux[tw], c.ones_C, c.zeros_C, 1e-5, C, dt, add=Lr.pos[tw], add_period=P,
+                                      add_mode=1)
+                kvs.append(ops.gemm(xn, Lr.kv[tw].w, Lr.kv[tw].b))            # [T*P, 2C]: K | V
+            qn, _ = ops.layernorm(qin, Lr.q_ln[0], Lr.q_ln[1], 1e-5, C, dt)
+            qs = ops.gemm(qn, Lr.q_proj.w)
+            att = ops.sva_attention(qs, kvs, mask, T, side, r, C, 16)
+            q2 = ops.gemm(att, Lr.o_proj.w, res=qin, out_f32=True)            # queries + attention_output
+            qn2, _ = ops.layernorm(q2, Lr.norm[0], Lr.norm[1], 1e-5, C, dt)
+            h = ops.gemm(qn2, Lr.out1.w, act=L.ACT_GELU_ERF)
+            q16 = ops.gemm(h, Lr.out2.w, res=q16)                             # + residual (layer input)
+        return q16
+
+    def mm_project(self, q16):
+        h = ops.gemm(q16, self.c.mm1.w, self.c.mm1.b, act=L.ACT_GELU_ERF)
+        return ops.gemm(h, self.c.mm2.w, self.c.mm2.b)
+
+    def unpad_newline(self, feat, T, image_sizes):
+        """feat [T*nq, Hp] -> X [T*N, Hp] with the newline column appended (all frames of a video share image_size)."""
+        side = self.side
+        src, sizes = [], []
+        cache = {}
+        for t in range(T):
+            key = tuple(image_sizes[t])
+            if key not in cache:
+                cache[key] = seg.unpad_newline_map(side, key, 0)
+            m, sz = cache[key]
+            src.extend((k, r + (t * side * side if k == 0 else 0)) for (k, r) in m)
+            sizes.append(sz)
+        idx = torch.tensor(src, dtype=torch.int32, device=self.dev).contiguous()
+        Hp = feat.shape[1]
+        X = ops.gather_rows([feat, self.c.image_newline], idx, len(src), Hp)
+        return X, sizes
+
+    def connector(self, sig_feat, dino_feat, T, image_sizes, keep=None):
+        aux = [self.aux_project(sig_feat, 0), self.aux_project(dino_feat, 1)]
+        q = self.sva(aux, T, image_sizes)
+        feat = self.mm_project(q)
+        X, sizes = self.unpad_newline(feat, T, image_sizes)
+        if keep is not None:
+            keep.update(aux0=aux[0], aux1=aux[1], sva=q, mm_proj=feat)
+        return X, sizes
+
+    # ------------------------------------------------------------------------------------------------ a11-a19
+    def qformer(self, enc, F, Nenc, query, qsrc, prompt_ids):
+        """Batched Q-Former (tdc/Qformer.py:804-965) over F compressed frames.
+        enc [F*Nenc, Hp] 16-bit; query [nC*K, Dq_pad] (query_proj output per chunk); qsrc int32 [F] chunk of frame.
+        Returns last hidden state rows of the K query tokens as the combined buffer h16 [F*S, Dq_pad] and S."""
+        qf, dt = self.c.qformer, self.dtype
+        Dq = qf.dim
+        K = self.K
+        heads = self.qheads
+        hd = Dq // heads
+        ids = None
+        if prompt_ids is not None and len(prompt_ids) > 0:
+            ids = torch.as_tensor(prompt_ids, dtype=torch.int32, device=self.dev).contiguous()
+        Lt = 0 if ids is None else ids.numel()
+        S = K + Lt
+        h32, h16 = ops.qformer_embed(query, qsrc, qf.word, qf.pos, ids, qf.emb_ln[0], qf.emb_ln[1], 1e-12, F, K, Dq, dt)
+        kv_all = ops.gemm(enc, qf.cross_kv.w, qf.cross_kv.b)                  # [F*Nenc, n_cross*2*Dq]
+        Dp = h16.shape[1]
+        ctx = torch.zeros(F * S, Dp, device=self.dev, dtype=dt)
+        ctx_q = torch.zeros(F * K, Dp, device=self.dev, dtype=dt)
+        t32 = torch.empty(F * S, Dp, device=self.dev, dtype=torch.float32)
+        scale = 1.0 / math.sqrt(hd)
+        qmap = (K, S, 0, 1)
+        tmap = (Lt, S, K, 1) if Lt else None
+        for Lr in qf.layers:
+            qkv = ops.gemm(h16, Lr.qkv.w, Lr.qkv.b)
+            ld = qkv.stride(0)
+            ops.attention(qkv[:, 0:Dq], qkv[:, Dq:2 * Dq], qkv[:, 2 * Dq:3 * Dq], ctx, F, heads, hd, S, S, scale,
+                          S * ld, S * ld, S * ld, S * ctx.stride(0))
+            ops.gemm(ctx, Lr.attn_out.w, Lr.attn_out.b, res=h32, out=t32, out_f32=True)
+            ops.layernorm(t32, Lr.attn_ln[0], Lr.attn_ln[1], 1e-12, Dq, dt, y16=h16, y32=h32)
+            if Lr.cross is not None:
+                cq = ops.gemm(h16, Lr.cross.q.w, Lr.cross.q.b, M=F * K, a_map=qmap)          # [F*K, Dq]
+                j = Lr.cross.idx
+                kk = kv_all[:, j * 2 * Dq: j * 2 * Dq + Dq]
+                vv = kv_all[:, j * 2 * Dq + Dq: (j + 1) * 2 * Dq]
+                ldk = kv_all.stride(0)
+                ops.attention(cq[:, :Dq], kk, vv, ctx_q, F, heads, hd, K, Nenc, scale, K * cq.stride(0), Nenc * ldk,
+                              Nenc * ldk, K * ctx_q.stride(0))
+                ops.gemm(ctx_q, Lr.cross.out.w, Lr.cross.out.b, res=h32, r_map=qmap, out=t32, out_f32=True, M=F * K)
+                ops.layernorm(t32, Lr.cross.ln[0], Lr.cross.ln[1], 1e-12, Dq, dt, y16=h16, y32=h32, rows=F * K,
+                              y_map=qmap)
+            m = ops.gemm(h16, Lr.ffn_q.fc1.w, Lr.ffn_q.fc1.b, act=L.ACT_GELU_ERF, M=F * K, a_map=qmap)
+            ops.gemm(m, Lr.ffn_q.fc2.w, Lr.ffn_q.fc2.b, res=h32, r_map=qmap, out=t32, out_f32=True, M=F * K)
+            if Lt:
+                m2 = ops.gemm(h16, Lr.ffn_t.fc1.w, Lr.ffn_t.fc1.b, act=L.ACT_GELU_ERF, M=F * Lt, a_map=tmap)
+                t32b = ops.gemm(m2, Lr.ffn_t.fc2.w, Lr.ffn_t.fc2.b, res=h32, r_map=tmap, out_f32=True, M=F * Lt)
+            ops.layernorm(t32, Lr.ffn_q.ln[0], Lr.ffn_q.ln[1], 1e-12, Dq, dt, y16=h16, y32=h32, rows=F * K, y_map=qmap)
+            if Lt:
+                ops.layernorm(t32b, Lr.ffn_t.ln[0], Lr.ffn_t.ln[1], 1e-12, Dq, dt, y16=h16, y32=h32, rows=F * Lt,
+                              y_map=tmap)
+        return h16, S
+
+    def compress(self, X, T, N, seg_indices, prompt_ids, max_visual_len, audio=None, keep=None):
+        """X [T*N, Hp] -> emitted visual tokens [n, H] (tdc/cambrian_arch.py:1520-1709)."""
+        c, dt, dev = self.c, self.dtype, self.dev
+        H, Hp = c.H, pad64(c.H)
+        K = self.K
+        Na = 0
+        Xf = X
+        if audio is not None:
+            # a20: frames become [visual N | audio_proj(audio) 50] (cambrian_arch.py:1611-1614)
+            Na = audio.shape[1]
+            A16 = torch.zeros(T * Na, pad64(audio.shape[2]), device=dev, dtype=dt)
+            A16[:, : audio.shape[2]] = audio.reshape(T * Na, -1).to(dt)
+            Xf = torch.empty(T * (N + Na), Hp, device=dev, dtype=dt)
+            Xf.view(T, N + Na, Hp)[:, :N].copy_(X.view(T, N, Hp))          # visual rows (device copy)
+            ops.gemm(A16, c.audio_proj.w, c.audio_proj.b, out=Xf, c_map=(Na, N + Na, N, 1))   # audio rows
+        Nf = N + Na
+        plan = seg.emit_plan(T, Nf, K, seg_indices, max_visual_len)
+        comp_frames = plan["comp_frames"]
+        F = len(comp_frames)
+        comp = None
+        if F > 0:
+            nC = len(plan["key_frames"])
+            keys = torch.tensor(plan["key_frames"], dtype=torch.int32, device=dev)
+            pooled = ops.adaptive_pool_tokens(Xf, N, K, nC, keys, frame_rows=Nf)        # visual-only key frame
+            query = ops.gemm(pooled, c.query_proj.w, c.query_proj.b)                    # [nC*K, Dq_pad]
+            enc_idx = torch.tensor([(0, f * Nf + i) for f in comp_frames for i in range(Nf)], dtype=torch.int32,
+                                   device=dev)
+            enc = ops.gather_rows([Xf], enc_idx, F * Nf, Hp)
+            qsrc = torch.tensor(plan["comp_chunk"], dtype=torch.int32, device=dev)
+            h16, S = self.qformer(enc, F, Nf, query, qsrc, prompt_ids)
+            comp = ops.gemm(h16, c.vision_proj.w, c.vision_proj.b, M=F * K, a_map=(K, S, 0, 1))
+            ops.l2_normalize(comp, F * K, H)
+            if keep is not None:
+                keep.update(compressed=comp, last_hidden=h16, S=S)
+        # emission: one gather over (static frame tokens | context tokens | frame_seg)
+        tab = {"f": 0, "c": 1, "s": 2}
+        src = []
+        for e in plan["src"]:
+            if e[0] == "f":
+                src.append((0, e[1] * Nf + e[2]))
+            elif e[0] == "c":
+                src.append((1, e[1] * K + e[2]))
+            else:
+                src.append((2, 0))
+        idx = torch.tensor(src, dtype=torch.int32, device=dev).contiguous()
+        tables = [Xf, comp if comp is not None else c.frame_seg, c.frame_seg]
+        out = ops.gather_rows(tables, idx, len(src), H)
+        if keep is not None:
+            keep["plan"] = plan
+        return out
+
+    # ------------------------------------------------------------------------------------------------ top level
+    def encode_video(self, px_siglip, px_dino, image_size, budget_text_len, n_text_tokens, prompt_ids, audio=None,
+                     frame_cap=224, keep=None):
+        """One video: pixels -> emitted visual tokens [n, H] (S0-S10).  `budget_text_len` is the text length used by
+        get_max_num_frames (cambrian_arch.py:753-759), `n_text_tokens` the non-image token count (:1499-1505)."""
+        cfg = self.cfg
+        T0 = px_siglip.shape[0]
+        idx = seg.uniform_indices(T0, min(seg.get_max_num_frames(budget_text_len, cfg), frame_cap))     # a1
+        if len(idx) != T0:
+            sel = torch.tensor(idx, device=px_siglip.device)
+            px_siglip, px_dino = px_siglip[sel], px_dino[sel]
+        T = len(idx)
+        dino = self.tower("dino", px_dino)                                                              # a4
+        mns = cfg.get("max_num_segments", 24)
+        if T <= mns + 1:                                                                                 # a5
+            sel2, seg_idx = list(range(T)), list(range(T))
+        else:
+            sel2 = seg.uniform_indices(T, frame_cap)
+            if len(sel2) != T:
+                s2 = torch.tensor(sel2, device=px_siglip.device)
+                P = dino.shape[0] // T
+                dino = dino.view(T, P, -1)[s2].reshape(len(sel2) * P, -1)
+                px_siglip = px_siglip[s2]
+                T = len(sel2)
+            sims = self.frame_sims(dino, T)
+            seg_idx = seg.select_segments(sims, mns)
+        sig = self.tower("siglip", px_siglip)                                                           # a3
+        sizes = [tuple(image_size)] * T
+        X, final_size = self.connector(sig, dino, T, sizes, keep)                                       # a6-a10
+        N = X.shape[0] // T
+        max_visual_len = cfg["tokenizer_model_max_length"] - cfg.get("inference_max_length", 16) - n_text_tokens
+        pid = prompt_ids if cfg.get("text_input", True) else None
+        vis = self.compress(X, T, N, seg_idx, pid, max_visual_len, audio, keep)                         # a11-a19
+        if keep is not None:
+            keep.update(frame_indices=idx, selected=sel2, seg_indices=seg_idx, siglip_feat=sig, dino_feat=dino,
+                        final_size=final_size, X=X)
+        return vis

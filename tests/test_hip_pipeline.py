@@ -1,0 +1,150 @@
+"""GPU parity of the HIP pipeline against the oracle AND the reference-generated golden fixtures (run with -m gpu).
+
+Tolerances (stated per north_star: 1e-3 fp16 atol on the compressed context tokens; stage outputs are compared with
+an error relative to the stage's magnitude because raw ViT / projector activations are O(1-40) where one fp16 ulp is
+already > 1e-3):
+   compressed context tokens (L2-normalised, |x| ~ 1/sqrt(H))  atol 1e-3          fp16
+   stage outputs                                               max|err| <= 4e-3 * max|ref|   fp16 (3e-2 bf16)
+   integers (frame / segment indices, sizes, token layout)     bit-exact
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from util import oracle, load_fixture, embed_fn, pipeline_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), torch.as_tensor(b).float()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item()
+
+
+def stage_tol(dtype):
+    return 4e-3 if dtype == torch.float16 else 3e-2
+
+
+def make_encoder(W, cfg, dtype):
+    import tdc_video_amd  # noqa: F401
+    from tdc_video_amd.pipeline import VideoEncoder
+    return VideoEncoder(W, cfg, dtype=dtype, device="cuda", siglip_heads=4, dino_heads=4, qformer_heads=4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_towers_vs_golden(dtype):
+    import tdc_video_amd  # noqa: F401
+    from tdc_video_amd import weights as Wt
+    from tdc_video_amd.pipeline import VideoEncoder
+    for name, prep, key in (("siglip_small.npz", "siglip", "vision_tower_aux_list.0.vision_tower."),
+                            ("dino_small.npz", "dino", "vision_tower_aux_list.1.vision_tower.")):
+        W, o = load_fixture(name)
+        enc = VideoEncoder.__new__(VideoEncoder)
+        enc.dtype, enc.dev, enc.tower_batch = dtype, torch.device("cuda"), 64
+        enc._tables = {}
+        enc.out_grid = [8, 8]
+        t = (Wt.prep_siglip if prep == "siglip" else Wt.prep_dino)(W, 4, dtype, enc.dev)
+        enc.towers = {prep: t}
+        px = torch.from_numpy(o["pixels"]).cuda()
+        out = enc.tower(prep, px)
+        D = t.dim
+        got = out[:, :D].reshape(px.shape[0], 64, D)
+        assert rel(got, o["out"]) < stage_tol(dtype), name
+        assert torch.count_nonzero(out[:, D:]) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_qformer_chunk_vs_golden(dtype):
+    """tdc/cambrian_arch.py:1629-1667 on one 6-frame chunk: compressed tokens within 1e-3 (fp16)."""
+    W, o = load_fixture("qformer_small.npz")
+    import tdc_video_amd  # noqa: F401
+    from tdc_video_amd import weights as Wt, ops
+    from tdc_video_amd.pipeline import VideoEncoder
+    H, K = 96, int(o["K"])
+    # minimal connector state around the Q-Former
+    sd = dict(W)
+    for k in ("mm_projector.0.weight", "mm_projector.2.weight"):
+        sd[k] = torch.zeros(H, H if k.endswith("2.weight") else 64)
+    sd["mm_projector.0.bias"] = torch.zeros(H); sd["mm_projector.2.bias"] = torch.zeros(H)
+    for i, dv in enumerate((48, 64)):
+        sd["mm_projector_aux_%d.0.weight" % i] = torch.zeros(64, dv); sd["mm_projector_aux_%d.0.bias" % i] = torch.zeros(64)
+        sd["mm_projector_aux_%d.2.weight" % i] = torch.zeros(64, 64); sd["mm_projector_aux_%d.2.bias" % i] = torch.zeros(64)
+        sd["mm_projector_aux_%d.3.weight" % i] = torch.ones(64); sd["mm_projector_aux_%d.3.bias" % i] = torch.zeros(64)
+    sd["vision_query"] = torch.zeros(1, 64); sd["image_newline"] = torch.zeros(H); sd["frame_seg"] = torch.arange(H).float() / H
+    cfg = dict(hidden_size=H, vision_hidden_size=64, context_token_num=K, query_num_list=[16],
+               tokenizer_model_max_length=8192)
+    enc = VideoEncoder(sd, cfg, dtype=dtype, device="cuda", qformer_heads=4)
+    chunk = torch.from_numpy(o["chunk"])                        # [6, N, H]
+    Tn, N, _ = chunk.shape
+    Hp = ops.pad64(H)
+    X = torch.zeros(Tn * N, Hp, device="cuda", dtype=dtype)
+    X[:, :H] = chunk.reshape(Tn * N, H).to(dtype).cuda()
+    keep = {}
+    # a single segment (no boundaries inside): seg index T-1 is the last frame -> chunk (0, T)
+    vis = enc.compress(X, Tn, N, [], [int(i) for i in o["prompt_ids"]], 10 ** 6, keep=keep)
+    comp = keep["compressed"][:, :H].reshape(Tn - 1, K, H)
+    err = (comp.float().cpu() - torch.from_numpy(o["out_compressed"])).abs().max().item()
+    assert err < (1e-3 if dtype == torch.float16 else 6e-3), err
+    # emitted layout: key frame (N) + sep, then (K + sep) per compressed frame
+    assert vis.shape == (N + 1 + (Tn - 1) * (K + 1), H)
+    assert torch.equal(vis[:N].cpu(), X[:N, :H].cpu())
+    assert torch.equal(vis[N].cpu(), enc.c.frame_seg[0, :H].cpu())
+    assert torch.equal(vis[N + 1:N + 1 + K].cpu(), keep["compressed"][:K, :H].cpu())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name", ["pipeline_T40.npz", "pipeline_T10_land.npz", "pipeline_T260.npz"])
+def test_full_pipeline_vs_golden(name, dtype):
+    W, o = load_fixture(name)
+    cfg = pipeline_cfg(o)
+    enc = make_encoder(W, cfg, dtype)
+    vid = torch.from_numpy(synth.video_from_basis(o["video_basis"], o["video_coef"]))
+    ids = torch.from_numpy(o["input_ids"])[0]
+    image_size = tuple(int(v) for v in o["image_size"])
+    keep = {}
+    vis = enc.encode_video(vid.cuda(), (vid + 0.01).cuda(), image_size, budget_text_len=len(ids),
+                           n_text_tokens=len(ids) - 1, prompt_ids=[int(i) for i in o["prompt_ids"]], keep=keep)
+    T = len(keep["selected"])
+    stride = 16 if "T260" in name else 1
+    # integers
+    assert keep["seg_indices"] == o["out_seg_indices"].tolist()
+    assert keep["selected"] == o["out_selected"].tolist()
+    assert [list(s) for s in keep["final_size"]] == o["out_final_size"].tolist()
+    tol = stage_tol(dtype)
+
+    def stage(key, ref, cols):
+        g = keep[key][:, :cols].reshape(T, -1, cols)[::stride]
+        assert rel(g, ref) < tol, key
+    stage("siglip_feat", o["out_siglip_feat"], 48)
+    stage("dino_feat", o["out_dino_feat"], 64)
+    stage("aux0", o["out_aux0"], 64)
+    stage("aux1", o["out_aux1"], 64)
+    stage("sva", o["out_sva"], 64)
+    stage("mm_proj", o["out_mm_proj"], 96)
+    # final: splice text embeddings around the visual tokens exactly as the reference does (a21)
+    emb = embed_fn(o)
+    pos = int(torch.where(ids == -200)[0][0])
+    full = torch.cat([emb(ids[:pos]), vis.float().cpu(), emb(ids[pos + 1:])])[: cfg["tokenizer_model_max_length"]]
+    ref = torch.from_numpy(o["out_inputs_embeds"])[0]
+    assert full.shape == ref.shape
+    assert rel(full, ref) < tol
+    if int(o["n_qformer_calls"]) > 0:
+        # compressed tokens are unit-norm rows: the north_star 1e-3 atol applies
+        comp = keep["compressed"][:, :96].float().cpu()
+        W["embed_tokens_fn"] = emb
+        r = oracle.encode_video(W, cfg, vid, vid + 0.01, image_size, torch.from_numpy(o["input_ids"]),
+                                torch.from_numpy(o["prompt_ids"]))
+        plan = keep["plan"]
+        # oracle compressed tokens, recovered from its emitted stream through the same plan
+        ref_rows = {}
+        for i, e in enumerate(plan["src"]):
+            if e[0] == "c":
+                ref_rows[(e[1], e[2])] = r["visual_tokens"][i]
+        got = torch.stack([comp[a * 4 + b] for (a, b) in ref_rows])
+        want = torch.stack(list(ref_rows.values()))
+        err = (got - want).abs().max().item()
+        assert err < (1e-3 if dtype == torch.float16 else 8e-3), err
