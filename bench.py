@@ -1,0 +1,295 @@
+"""bench.py - frames/s of TDC-Video's video-encoding hot path (encode + compress) on N MI355X GPUs of one node.
+
+  python bench.py --gpus 1 --steps K --warmup W                      (N=1)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W   (N>1, one rank/GPU)
+
+A "step" = one pass of the hot path (S0-S10 of SURVEY.md 3.2: DINOv2-g + SigLIP-so400m towers, adjacent-frame
+segmentation, aux projectors, SVA 576->144, mm_projector, unpad/newline, batched Q-Former TDC compressor,
+vision_proj + L2, token emission) over ONE synthetic video of T frames whose pixels are already resident in HBM.
+For N>1 the T frames of the one video are sharded by contiguous ranges over the ranks (strong scaling), with the RCCL
+exchanges of tdc-video_amd/dist.py (similarities all-gather, key-frame query hand-off, emitted-token all-gather).
+Prints ONE JSON line on rank 0 (contract in the task statement) incl. `roofline` (dominant kernel = tdc_gemm MFMA
+kernel, timed live with events on the launch stream) and `cpu_baseline` (the oracle on the host cores, bounded sample).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0   # dense bf16/fp16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def model_cfg(H, K, T):
+    return dict(hidden_size=H, vision_hidden_size=1024, num_query_group=1, query_num_list=[144], image_token_len=144,
+                mm_vision_tower_aux_token_len_list=[576, 576], connector_depth=3, context_token_num=K,
+                tokenizer_model_max_length=10 ** 9, inference_max_length=16, max_num_segments=24, model_type="qwen2",
+                text_input=True, add_static=True)
+
+
+def random_state_dict(H, K, device, gen, siglip_px=384, dino_pos_grid=37, std=0.02):
+    """Random-init weights of the reference architecture, reference state-dict names, fp32."""
+    sd = {}
+
+    def w(name, *shape, s=std):
+        sd[name] = torch.randn(*shape, device=device, generator=gen) * s
+
+    def ln(name, n):
+        sd[name + ".weight"] = 1.0 + 0.05 * torch.randn(n, device=device, generator=gen)
+        sd[name + ".bias"] = 0.02 * torch.randn(n, device=device, generator=gen)
+
+    def lin(name, n, k, bias=True):
+        w(name + ".weight", n, k)
+        if bias:
+            w(name + ".bias", n)
+    # SigLIP-so400m/14: 1152, 27 layers, 16 heads, MLP 4304
+    p = "vision_tower_aux_list.0.vision_tower."
+    D = 1152
+    w(p + "embeddings.patch_embedding.weight", D, 3, 14, 14); w(p + "embeddings.patch_embedding.bias", D)
+    w(p + "embeddings.position_embedding.weight", (siglip_px // 14) ** 2, D)
+    for i in range(27):
+        q = p + "encoder.layers.%d." % i
+        ln(q + "layer_norm1", D); ln(q + "layer_norm2", D)
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            lin(q + "self_attn." + n, D, D)
+        lin(q + "mlp.fc1", 4304, D); lin(q + "mlp.fc2", D, 4304)
+    # DINOv2-giant/14: 1536, 40 layers, 24 heads, SwiGLU 4096, LayerScale
+    p = "vision_tower_aux_list.1.vision_tower."
+    D = 1536
+    w(p + "embeddings.patch_embeddings.projection.weight", D, 3, 14, 14)
+    w(p + "embeddings.patch_embeddings.projection.bias", D)
+    w(p + "embeddings.cls_token", 1, 1, D); w(p + "embeddings.position_embeddings", 1, 1 + dino_pos_grid ** 2, D)
+    for i in range(40):
+        q = p + "encoder.layer.%d." % i
+        ln(q + "norm1", D); ln(q + "norm2", D)
+        for n in ("query", "key", "value"):
+            lin(q + "attention.attention." + n, D, D)
+        lin(q + "attention.output.dense", D, D)
+        sd[q + "layer_scale1.lambda1"] = torch.full((D,), 1.0, device=device)
+        sd[q + "layer_scale2.lambda1"] = torch.full((D,), 1.0, device=device)
+        lin(q + "mlp.weights_in", 8192, D); lin(q + "mlp.weights_out", D, 4096)
+    ln(p + "layernorm", D)
+    # connector
+    C = 1024
+    for i, dv in enumerate((1152, 1536)):
+        q = "mm_projector_aux_%d." % i
+        lin(q + "0", C, dv); lin(q + "2", C, C); ln(q + "3", C)
+    w("vision_query", 1, C, s=1.0)
+    for i in range(3):
+        q = "vision_sampler_0.layers.%d." % i
+        w(q + "pos_embed_0", 4, C, s=1.0); w(q + "pos_embed_1", 4, C, s=1.0)
+        lin(q + "proj_context", C, C, False); lin(q + "proj_in", C, 2 * C, False)
+        lin(q + "proj_out.linear_1", C, C, False); lin(q + "proj_out.linear_2", C, C, False)
+        ln(q + "norm", C)
+        ln(q + "cross_attn.q_proj.0", C); lin(q + "cross_attn.q_proj.1", C, C, False)
+        for tw in range(2):
+            for kv in "kv":
+                ln(q + "cross_attn.%s_proj_%d.0" % (kv, tw), C); lin(q + "cross_attn.%s_proj_%d.1" % (kv, tw), C, C, False)
+        lin(q + "cross_attn.o_proj", C, C, False)
+    lin("mm_projector.0", H, C); lin("mm_projector.2", H, H)
+    w("image_newline", H, s=1.0); w("frame_seg", H, s=1.0)
+    # Q-Former (bert-base: 12 x 768, 12 heads, FFN 3072, cross-attention in even layers)
+    Dq = 768
+    q = "Qformer.bert."
+    w(q + "embeddings.word_embeddings.weight", 30522, Dq); w(q + "embeddings.position_embeddings.weight", 512, Dq)
+    ln(q + "embeddings.LayerNorm", Dq)
+    for i in range(12):
+        l = q + "encoder.layer.%d." % i
+        for n in ("query", "key", "value"):
+            lin(l + "attention.self." + n, Dq, Dq)
+        lin(l + "attention.output.dense", Dq, Dq); ln(l + "attention.output.LayerNorm", Dq)
+        if i % 2 == 0:
+            lin(l + "crossattention.self.query", Dq, Dq)
+            lin(l + "crossattention.self.key", Dq, H); lin(l + "crossattention.self.value", Dq, H)
+            lin(l + "crossattention.output.dense", Dq, Dq); ln(l + "crossattention.output.LayerNorm", Dq)
+        for a, b in (("intermediate", "output"), ("intermediate_query", "output_query")):
+            lin(l + a + ".dense", 3072, Dq); lin(l + b + ".dense", Dq, 3072); ln(l + b + ".LayerNorm", Dq)
+    lin("query_proj", Dq, H); lin("vision_proj", H, Dq)
+    return sd
+
+
+def synth_video(lo, hi, px, device, dtype, seed=1234, scene_len=21):
+    """frames [lo, hi) of a deterministic synthetic video (scene = constant base image + per-frame noise)."""
+    g = torch.Generator(device=device)
+    out = torch.empty(hi - lo, 3, px, px, device=device, dtype=dtype)
+    for t in range(lo, hi):
+        sc = t // scene_len
+        g.manual_seed(seed * 7919 + sc)
+        base = torch.rand(3, px, px, device=device, generator=g) * 2 - 1
+        g.manual_seed(seed * 104729 + 1000003 + t)
+        out[t - lo] = (base + 0.1 * torch.randn(3, px, px, device=device, generator=g)).to(dtype)
+    return out
+
+
+def cpu_baseline(sd_cpu, cfg, H, K, px_s, px_d, budget_s=25.0):
+    """The oracle (CPU restatement, torch fp32 eager) timed on this host's cores on a bounded sample of the same
+    workload: towers on n_v frames, connector + compressor on a 32-frame clip; per-frame costs are added."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import tdc_oracle as orc
+    cores = torch.get_num_threads()
+    W = dict(sd_cpu)
+    Ws = {k[len("vision_tower_aux_list.0.vision_tower."):]: v for k, v in W.items() if k.startswith("vision_tower_aux_list.0.")}
+    Wd = {k[len("vision_tower_aux_list.1.vision_tower."):]: v for k, v in W.items() if k.startswith("vision_tower_aux_list.1.")}
+    g = torch.Generator().manual_seed(1)
+    t0 = time.time()
+    n_v = 0
+    with torch.no_grad():
+        while True:
+            x = torch.rand(1, 3, px_s, px_s, generator=g) * 2 - 1
+            orc.siglip_tower(x, Ws, 16)
+            y = torch.rand(1, 3, px_d, px_d, generator=g) * 2 - 1
+            orc.dino_tower(y, Wd, 24)
+            n_v += 1
+            if time.time() - t0 > budget_s * 0.5 or n_v >= 4:
+                break
+        t_v = (time.time() - t0) / n_v
+        # compressor stage on a 32-frame clip of post-tower features
+        Tc = 32
+        sig = torch.randn(Tc, 576, 1152, generator=g)
+        din = torch.randn(Tc, 576, 1536, generator=g)
+        t1 = time.time()
+        aux = [orc.mm_projector_aux(sig, W, 0), orc.mm_projector_aux(din, W, 1)]
+        q, _ = orc.sva(aux, W["vision_query"][0], [(384, 384)] * Tc, W, 12)
+        feat = orc.mm_projector(q, W)
+        frames, _ = orc.unpad_newline(feat, [(384, 384)] * Tc, W["image_newline"])
+        sims = orc.adjacent_cosine(din)
+        seg = orc.select_segments(sims, 24)
+        orc.tdc_compress(torch.stack(frames), seg, torch.arange(12) + 1000, W, K, 12, 10 ** 9)
+        t_c = (time.time() - t1) / Tc
+    fps = 1.0 / (t_v + t_c)
+    return dict(value=round(fps, 4), unit="frames/s", cores=cores, kind="port",
+                sample="oracle/tdc_oracle.py fp32 eager: both towers on %d frame(s) (%.2f s/frame) + connector & "
+                       "TDC compressor on a 32-frame clip (%.3f s/frame), per-frame costs added" % (n_v, t_v, t_c))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=512)
+    ap.add_argument("--K", type=int, default=144, help="context_token_num (BASELINE configs: 144; reference default 16)")
+    ap.add_argument("--hidden", type=int, default=3584, help="LLM embed dim (Qwen2-7B)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--px", type=int, default=384, help="SigLIP input size (DINO uses px-6: 378); 336 -> 336/336")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tower-batch", type=int, default=64)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    import tdc_video_amd  # noqa: F401
+    from tdc_video_amd import ops
+    from tdc_video_amd.pipeline import VideoEncoder
+    from tdc_video_amd import segment as seg
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    T, K, H = args.frames, args.K, args.hidden
+    px_s = args.px
+    px_d = args.px - 6 if args.px == 384 else args.px
+    cfg = model_cfg(H, K, T)
+    gen = torch.Generator(device=dev).manual_seed(0)
+    sd = random_state_dict(H, K, dev, gen, siglip_px=px_s)
+    enc = VideoEncoder(sd, cfg, dtype=dtype, device=dev, siglip_heads=16, dino_heads=24, qformer_heads=12,
+                       tower_batch=args.tower_batch)
+    sd_cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sd_cpu = {k: v.cpu() for k, v in sd.items()}
+    del sd
+    torch.cuda.empty_cache()
+
+    prompt_ids = [101] + list(range(2000, 2010)) + [102]          # 12 BERT ids
+    lo, hi = seg.shard_ranges(T, world)[rank]
+    if world == 1:
+        vs = synth_video(0, T, px_s, dev, dtype)
+        vd = synth_video(0, T, px_d, dev, dtype, seed=4321) if px_d != px_s else vs
+
+        def step():
+            return enc.encode_video(vs, vd, (384, 384), budget_text_len=64, n_text_tokens=64, prompt_ids=prompt_ids,
+                                    frame_cap=T)
+    else:
+        from tdc_video_amd import dist as tdist
+        halo = 1 if rank < world - 1 else 0
+        vs = synth_video(lo, hi, px_s, dev, dtype)
+        vd = synth_video(lo, hi + halo, px_d, dev, dtype, seed=4321 if px_d != px_s else 1234)
+        sharded = tdist.ShardedVideoEncoder(enc, rank, world)
+
+        def step():
+            return sharded.encode_video(vs, vd, T, (384, 384), n_text_tokens=64, prompt_ids=prompt_ids)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    fps = T * args.steps / dt
+
+    # ---- roofline of the dominant kernel (tdc_gemm MFMA kernel): one extra profiled pass, events on the launch stream
+    ops.PROFILE = {"gemm": [], "attn": []}
+    step()
+    torch.cuda.synchronize()
+    prof = ops.PROFILE
+    ops.PROFILE = None
+    g_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof["gemm"])
+    g_fl = sum(w for _, _, w in prof["gemm"])
+    a_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof["attn"])
+    a_fl = sum(w for _, _, w in prof["attn"])
+    # the north_star's cross-attention block = the stacked K/V projection GEMM (+ tiny QK^T/PV): report it separately
+    kv = [(e0.elapsed_time(e1), w) for e0, e1, w in prof["gemm"] if abs(w - max(x[2] for x in prof["gemm"])) < 1]
+    achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+    roofline = dict(bound="mfma", achieved=round(achieved, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=round(achieved / MFMA_PEAK_TFLOPS, 4), traffic=None, kernel="gemm_kernel (tdc_gemm)",
+                    launches=len(prof["gemm"]), avg_launch_us=round(g_ms * 1e3 / max(1, len(prof["gemm"])), 2),
+                    gemm_ms_per_step=round(g_ms, 2), gemm_tflop_per_step=round(g_fl / 1e12, 2),
+                    attention=dict(ms_per_step=round(a_ms, 2),
+                                   tflops=round(a_fl / (a_ms * 1e-3) / 1e12, 1) if a_ms > 0 else None,
+                                   launches=len(prof["attn"])),
+                    xattn_kv_gemm_tflops=round(sum(w for _, w in kv) / (sum(t for t, _ in kv) * 1e-3) / 1e12, 1)
+                    if kv else None)
+    if rank != 0:
+        return
+    res = {
+        "metric": "frames/sec encoded+compressed (576->K tokens) at T=%d" % T,
+        "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "one %d-frame video, SigLIP-so400m/14@%d + DINOv2-giant/14@%d towers (729 patches -> 576 "
+                               "tokens), SVA 576->144, mm_projector -> H=%d, Q-Former TDC K=%d (N=156, 12 prompt ids), "
+                               "random-init weights, frame cap lifted to T, LLM stubbed" % (T, px_s, px_d, H, K),
+                   "frames": T, "K": K, "hidden": H, "parallelism": "frames sharded over %d GPU(s)" % world,
+                   "emitted_tokens": int(out.shape[0])},
+        "roofline": roofline,
+    }
+    if sd_cpu is not None:
+        res["cpu_baseline"] = cpu_baseline(sd_cpu, cfg, H, K, px_s, px_d)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -9,6 +9,26 @@ import torch
 from . import lib as L
 
 
+# bench.py sets PROFILE to a dict to time kernels with events on the launch stream: {"gemm": [(e0, e1, flops)], ...}
+PROFILE = None
+
+
+def _prof_begin(kind):
+    if PROFILE is None or kind not in PROFILE:
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return e0
+
+
+def _prof_end(kind, e0, work):
+    if e0 is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    PROFILE[kind].append((e0, e1, work))
+
+
 def _dt(t):
     if t.dtype == torch.float16:
         return L.F16
@@ -90,7 +110,11 @@ def gemm(a, w, bias=None, act=L.ACT_NONE, res=None, out=None, out_f32=False, M=N
     d.M, d.N, d.K = M, N, K
     d.dtype, d.out_f32, d.act = _dt(a), int(out_f32), act
     d.a_map, d.c_map, d.r_map = _map(a_map), _map(c_map), _map(r_map)
+    e0 = _prof_begin("gemm")
     L.check(L.load().tdc_gemm(C.byref(d), _stream()), "tdc_gemm")
+    if e0 is not None:
+        rn, rk = getattr(w, "_real_nk", (N, K))
+        _prof_end("gemm", e0, 2.0 * M * rn * rk)
     return out
 
 
@@ -145,7 +169,9 @@ def attention(q, k, v, out, batch, heads, head_dim, sq, sk, scale, q_bs, k_bs, v
     d.q_rs, d.k_rs, d.v_rs, d.o_rs = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
     d.batch, d.heads, d.head_dim, d.sq, d.sk = batch, heads, head_dim, sq, sk
     d.scale, d.dtype = scale, _dt(q)
+    e0 = _prof_begin("attn")
     L.check(L.load().tdc_attention(C.byref(d), _stream()), "tdc_attention")
+    _prof_end("attn", e0, 4.0 * batch * heads * sq * sk * head_dim)
     return out
 
 

@@ -28,30 +28,34 @@ class Lin:
 
 
 def make_lin(W, b, dtype, dev, row_scale=None, col_scale=None, col_shift=None, n_pad=None, k_pad=None):
-    """W [n,k] fp32 (cpu).  Effective op: y = row_scale * (W @ (col_scale * x + col_shift) + b)."""
-    W = W.detach().to(torch.float32).cpu()
+    """W [n,k].  Effective op: y = row_scale * (W @ (col_scale * x + col_shift) + b).  The folding arithmetic runs in
+    fp32 on whatever device W lives on (one-time weight preparation), the result is cast and moved to `dev`."""
+    W = W.detach().to(torch.float32)
+    wd = W.device
     n, k = W.shape
-    bias = b.detach().to(torch.float32).cpu().clone() if b is not None else None
+    bias = b.detach().to(torch.float32).to(wd).clone() if b is not None else None
     if col_shift is not None:
-        extra = W @ col_shift.to(torch.float32).cpu()
+        extra = W @ col_shift.detach().to(torch.float32).to(wd)
         bias = extra if bias is None else bias + extra
     if col_scale is not None:
-        W = W * col_scale.to(torch.float32).cpu()[None, :]
+        W = W * col_scale.detach().to(torch.float32).to(wd)[None, :]
     if row_scale is not None:
-        rs = row_scale.to(torch.float32).cpu()
+        rs = row_scale.detach().to(torch.float32).to(wd)
         W = W * rs[:, None]
         if bias is not None:
             bias = bias * rs
     n_pad = pad64(n) if n_pad is None else n_pad
     k_pad = pad64(k) if k_pad is None else k_pad
-    Wp = torch.zeros(n_pad, k_pad, dtype=torch.float32)
-    Wp[:n, :k] = W
+    Wp = torch.zeros(n_pad, k_pad, dtype=dtype, device=wd)
+    Wp[:n, :k] = W.to(dtype)
     bp = None
     if bias is not None:
-        bp = torch.zeros(n_pad, dtype=torch.float32)
+        bp = torch.zeros(n_pad, dtype=torch.float32, device=wd)
         bp[:n] = bias
         bp = bp.to(dev)
-    return Lin(Wp.to(dtype).to(dev).contiguous(), bp, n, k)
+    w = Wp.to(dev).contiguous()
+    w._real_nk = (n, k)  # algorithmic dims for FLOP accounting (bench.py)
+    return Lin(w, bp, n, k)
 
 
 def stack_lins(parts, dtype, dev, k_pad=None, n_pad=None):
@@ -60,27 +64,27 @@ def stack_lins(parts, dtype, dev, k_pad=None, n_pad=None):
     any_b = any(p[1] is not None or (p[2] or {}).get("col_shift") is not None for p in parts)
     for W, b, kw in parts:
         kw = kw or {}
-        l = make_lin(W, b, torch.float32, "cpu", n_pad=W.shape[0], k_pad=W.shape[1], **kw)
+        l = make_lin(W, b, torch.float32, W.device, n_pad=W.shape[0], k_pad=W.shape[1], **kw)
         Ws.append(l.w)
         if any_b:
-            bs.append(l.b if l.b is not None else torch.zeros(W.shape[0]))
+            bs.append(l.b if l.b is not None else torch.zeros(W.shape[0], device=W.device))
     Wc = torch.cat(Ws, 0)
     bc = torch.cat(bs, 0) if any_b else None
     return make_lin(Wc, bc, dtype, dev, k_pad=k_pad, n_pad=n_pad)
 
 
 def vec32(v, dev, n_pad=None, fill=0.0):
-    v = v.detach().to(torch.float32).cpu().flatten()
+    v = v.detach().to(torch.float32).flatten()
     n_pad = pad64(v.numel()) if n_pad is None else n_pad
-    out = torch.full((n_pad,), fill, dtype=torch.float32)
+    out = torch.full((n_pad,), fill, dtype=torch.float32, device=v.device)
     out[: v.numel()] = v
     return out.to(dev)
 
 
 def mat32(m, dev, cols_pad=None):
-    m = m.detach().to(torch.float32).cpu()
+    m = m.detach().to(torch.float32)
     cols_pad = pad64(m.shape[1]) if cols_pad is None else cols_pad
-    out = torch.zeros(m.shape[0], cols_pad, dtype=torch.float32)
+    out = torch.zeros(m.shape[0], cols_pad, dtype=torch.float32, device=m.device)
     out[:, : m.shape[1]] = m
     return out.to(dev).contiguous()
 
@@ -165,14 +169,15 @@ def prep_dino(sd, heads, dtype, dev, patch=14, eps=1e-6):
                           row_scale=sd[p + "layer_scale1.lambda1"])
         Lr.ln2_g, Lr.ln2_b = vec32(sd[p + "norm2.weight"], dev), vec32(sd[p + "norm2.bias"], dev)
         if p + "mlp.weights_in.weight" in sd:
-            Win, bin_ = sd[p + "mlp.weights_in.weight"].float().cpu(), sd[p + "mlp.weights_in.bias"].float().cpu()
+            Win, bin_ = sd[p + "mlp.weights_in.weight"].float(), sd[p + "mlp.weights_in.bias"].float()
             hid = Win.shape[0] // 2
             hp = pad64(hid)
-            Wi = torch.zeros(2 * hp, Win.shape[1])
-            bi = torch.zeros(2 * hp)
+            Wi = torch.zeros(2 * hp, Win.shape[1], device=Win.device)
+            bi = torch.zeros(2 * hp, device=Win.device)
             Wi[0:2 * hid:2], Wi[1:2 * hid:2] = Win[:hid], Win[hid:]
             bi[0:2 * hid:2], bi[1:2 * hid:2] = bin_[:hid], bin_[hid:]
             Lr.fc1 = make_lin(Wi, bi, dtype, dev, n_pad=2 * hp)
+            Lr.fc1.w._real_nk = (2 * hid, Win.shape[1])
             Lr.fc2 = make_lin(sd[p + "mlp.weights_out.weight"], sd[p + "mlp.weights_out.bias"], dtype, dev,
                               row_scale=sd[p + "layer_scale2.lambda1"])
             t.act = "swiglu"
@@ -226,7 +231,7 @@ def prep_connector(sd, cfg, dtype, dev):
         c.aux.append(Namespace(fc1=make_lin(sd[p + "0.weight"], sd[p + "0.bias"], dtype, dev),
                                fc2=make_lin(sd[p + "2.weight"], sd[p + "2.bias"], dtype, dev),
                                ln_g=vec32(sd[p + "3.weight"], dev), ln_b=vec32(sd[p + "3.bias"], dev)))
-    c.vision_query = sd["vision_query"].detach().float().cpu()[0]
+    c.vision_query = sd["vision_query"].detach().float()[0]
     # SVA
     c.sva = []
     li = 0
@@ -235,7 +240,7 @@ def prep_connector(sd, cfg, dtype, dev):
         p = "vision_sampler_0.layers.%d." % li
         Lr = Namespace()
         Lr.proj_context = make_lin(sd[p + "proj_context.weight"], None, dtype, dev)
-        Win = sd[p + "proj_in.weight"].float().cpu()
+        Win = sd[p + "proj_in.weight"].float()
         Lr.proj_in_q = make_lin(Win[:, :C], None, dtype, dev)
         Lr.proj_in_c = make_lin(Win[:, C:], None, dtype, dev)
         Lr.q_ln = (vec32(sd[p + "cross_attn.q_proj.0.weight"], dev), vec32(sd[p + "cross_attn.q_proj.0.bias"], dev))
@@ -263,8 +268,8 @@ def prep_connector(sd, cfg, dtype, dev):
     Hp = pad64(H)
 
     def row16(v):
-        o = torch.zeros(1, Hp)
-        o[0, :H] = v.detach().float().cpu()
+        o = torch.zeros(1, Hp, device=v.device)
+        o[0, :H] = v.detach().float()
         return o.to(dtype).to(dev)
     c.image_newline = row16(sd["image_newline"])
     c.frame_seg = row16(sd["frame_seg"])
