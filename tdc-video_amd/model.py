@@ -1,0 +1,491 @@
+"""Host-side mirror of the reference's operator interface for the video-encoding path (the drop-in boundary):
+
+    CambrianMetaModel            tdc/cambrian_arch.py:47-484   (owns the parameters, same names / state-dict keys)
+    CambrianMetaForCausalLM      tdc/cambrian_arch.py:546-1898 (encode_images, adapt_segment,
+                                                                prepare_inputs_labels_for_multimodal -> 10-tuple)
+
+Same class / method / argument names, config keys and error behaviour, so `CambrianQwenForCausalLM.forward/.generate`
+(tdc/language_model/cambrian_qwen.py:260-284, :415-438) and the eval drivers call it unchanged.  All tensor math runs
+in libtdc_hip.so through `pipeline.VideoEncoder`; this file only holds parameters (nn.Parameter containers whose
+names reproduce the reference state dict), does the host integer logic and the text/visual splice (a21).
+
+Deliberate differences (documented in DESIGN.md): the dead `Qformer.cls` LM head is not allocated; the three aux
+return values used only by in-LLM samplers (`connector_only=False`) are returned as None; `video_indices=[None]`
+(what generate() passes) is treated as "not given" instead of raising TypeError when the frame cap triggers
+(tdc/cambrian_arch.py:919); training-only entry points raise NotImplementedError.
+"""
+import math
+from abc import ABC, abstractmethod
+
+import torch
+import torch.nn as nn
+
+from . import segment as seg
+from .pipeline import VideoEncoder
+
+IGNORE_INDEX = -100        # tdc/constants.py
+IMAGE_TOKEN_INDEX = -200
+
+
+class ParamTree(nn.Module):
+    """Container whose nested attribute names reproduce dotted state-dict keys ('0.weight', 'bert.encoder.layer.3...')."""
+
+    def __init__(self, spec=None, init=None):
+        super().__init__()
+        for name, shape in (spec or {}).items():
+            self.add(name, shape, init)
+
+    def add(self, name, shape, init=None):
+        head, _, rest = name.partition(".")
+        if rest:
+            if head not in self._modules:
+                self.add_module(head, ParamTree())
+            self._modules[head].add(rest, shape, init)
+        else:
+            p = nn.Parameter(torch.empty(*shape), requires_grad=False)
+            (init or _default_init)(name, p)
+            self.register_parameter(head, p)
+
+
+def _default_init(name, p):
+    with torch.no_grad():
+        if p.ndim >= 2:
+            p.normal_(0.0, 0.02)
+        elif "weight" in name or "lambda1" in name:
+            p.fill_(1.0)
+        else:
+            p.zero_()
+
+
+def _randn_init(name, p):
+    with torch.no_grad():
+        p.normal_(0.0, 1.0)
+
+
+# ------------------------------------------------------------------------------------------------ parameter specs
+def _linear(spec, name, n, k, bias=True):
+    spec[name + ".weight"] = (n, k)
+    if bias:
+        spec[name + ".bias"] = (n,)
+
+
+def _ln(spec, name, n):
+    spec[name + ".weight"] = (n,)
+    spec[name + ".bias"] = (n,)
+
+
+def qformer_spec(dq, layers, ffn, enc_width, vocab, max_pos, cross_freq=2):
+    s = {}
+    p = "bert."
+    s[p + "embeddings.word_embeddings.weight"] = (vocab, dq)
+    s[p + "embeddings.position_embeddings.weight"] = (max_pos, dq)
+    _ln(s, p + "embeddings.LayerNorm", dq)
+    for i in range(layers):
+        l = p + "encoder.layer.%d." % i
+        for n in ("query", "key", "value"):
+            _linear(s, l + "attention.self." + n, dq, dq)
+        _linear(s, l + "attention.output.dense", dq, dq)
+        _ln(s, l + "attention.output.LayerNorm", dq)
+        if i % cross_freq == 0:
+            _linear(s, l + "crossattention.self.query", dq, dq)
+            _linear(s, l + "crossattention.self.key", dq, enc_width)
+            _linear(s, l + "crossattention.self.value", dq, enc_width)
+            _linear(s, l + "crossattention.output.dense", dq, dq)
+            _ln(s, l + "crossattention.output.LayerNorm", dq)
+        for a, b in (("intermediate", "output"), ("intermediate_query", "output_query")):
+            _linear(s, l + a + ".dense", ffn, dq)
+            _linear(s, l + b + ".dense", dq, ffn)
+            _ln(s, l + b + ".LayerNorm", dq)
+    return s
+
+
+def sva_spec(C, depth, n_towers=2, r=2):
+    s = {}
+    for i in range(depth):
+        l = "layers.%d." % i
+        for t in range(n_towers):
+            s[l + "pos_embed_%d" % t] = (r * r, C)
+        _linear(s, l + "proj_context", C, C, False)
+        _linear(s, l + "proj_in", C, 2 * C, False)
+        _linear(s, l + "proj_out.linear_1", C, C, False)
+        _linear(s, l + "proj_out.linear_2", C, C, False)
+        _ln(s, l + "norm", C)
+        _ln(s, l + "cross_attn.q_proj.0", C)
+        _linear(s, l + "cross_attn.q_proj.1", C, C, False)
+        for t in range(n_towers):
+            for kv in "kv":
+                _ln(s, l + "cross_attn.%s_proj_%d.0" % (kv, t), C)
+                _linear(s, l + "cross_attn.%s_proj_%d.1" % (kv, t), C, C, False)
+        _linear(s, l + "cross_attn.o_proj", C, C, False)
+    return s
+
+
+def siglip_spec(D=1152, layers=27, mlp=4304, n_pos=729, patch=14):
+    s = {"embeddings.patch_embedding.weight": (D, 3, patch, patch), "embeddings.patch_embedding.bias": (D,),
+         "embeddings.position_embedding.weight": (n_pos, D)}
+    for i in range(layers):
+        l = "encoder.layers.%d." % i
+        _ln(s, l + "layer_norm1", D)
+        _ln(s, l + "layer_norm2", D)
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            _linear(s, l + "self_attn." + n, D, D)
+        _linear(s, l + "mlp.fc1", mlp, D)
+        _linear(s, l + "mlp.fc2", D, mlp)
+    return s
+
+
+def dino_spec(D=1536, layers=40, hidden=4096, n_pos=37 * 37, patch=14):
+    s = {"embeddings.cls_token": (1, 1, D), "embeddings.position_embeddings": (1, 1 + n_pos, D),
+         "embeddings.patch_embeddings.projection.weight": (D, 3, patch, patch),
+         "embeddings.patch_embeddings.projection.bias": (D,)}
+    for i in range(layers):
+        l = "encoder.layer.%d." % i
+        _ln(s, l + "norm1", D)
+        _ln(s, l + "norm2", D)
+        for n in ("query", "key", "value"):
+            _linear(s, l + "attention.attention." + n, D, D)
+        _linear(s, l + "attention.output.dense", D, D)
+        s[l + "layer_scale1.lambda1"] = (D,)
+        s[l + "layer_scale2.lambda1"] = (D,)
+        _linear(s, l + "mlp.weights_in", 2 * hidden, D)
+        _linear(s, l + "mlp.weights_out", D, hidden)
+    _ln(s, "layernorm", D)
+    return s
+
+
+class VisionTowerHandle:
+    """Stands where the reference keeps SiglipVisionTower / DinoVisionTower objects (a plain python list,
+    tdc/cambrian_arch.py:62; tdc/multimodal_encoder/builder.py:8-37).  `vision_tower` holds the HF-named parameters."""
+
+    def __init__(self, kind, name, arch):
+        self.kind, self.vision_tower_name = kind, name
+        self.arch = dict(arch)
+        self.hidden_size = arch["D"]
+        self.heads = arch["heads"]
+        self.is_loaded = False
+        self.vision_tower = None
+        self._interp_size = 576
+        self.image_size = 384 if kind == "siglip" else 378
+
+    def load_model(self, device_map=None, state_dict=None):
+        """Allocates the tower parameters (random init); pass `state_dict` (HF names) to load released weights - the
+        reference pulls them from the hub (siglip_encoder.py:28, dino_encoder.py:28), which this image cannot reach."""
+        a = self.arch
+        if self.kind == "siglip":
+            spec = siglip_spec(a["D"], a["layers"], a["mlp"], a["n_pos"])
+        else:
+            spec = dino_spec(a["D"], a["layers"], a["mlp"], a["n_pos"])
+        self.vision_tower = ParamTree(spec)
+        if state_dict is not None:
+            sd = {k.replace("vision_model.", ""): v for k, v in state_dict.items()}
+            self.vision_tower.load_state_dict(sd, strict=False)
+        self.is_loaded = True
+
+
+SIGLIP_SO400M = dict(D=1152, layers=27, mlp=4304, n_pos=729, heads=16)
+DINOV2_GIANT = dict(D=1536, layers=40, mlp=4096, n_pos=37 * 37, heads=24)
+
+
+def build_vision_tower_aux_list(config, tower_archs=None, **kwargs):
+    """tdc/multimodal_encoder/builder.py:8-37: tower picked by name ('siglip' / 'dinov2')."""
+    names = getattr(config, "mm_vision_tower_aux_list", getattr(config, "vision_tower_aux_list", None))
+    out = []
+    for i, n in enumerate(names):
+        if "siglip" in n.lower():
+            out.append(VisionTowerHandle("siglip", n, (tower_archs or {}).get("siglip", SIGLIP_SO400M)))
+        elif "dinov2" in n.lower():
+            out.append(VisionTowerHandle("dino", n, (tower_archs or {}).get("dino", DINOV2_GIANT)))
+        else:
+            raise ValueError(f"Unknown vision tower: {n}")
+    return out
+
+
+class CambrianMetaModel:
+    """Mixin placed before the HF base model in the MRO (tdc/cambrian_arch.py:47-181)."""
+
+    def __init__(self, config):
+        super(CambrianMetaModel, self).__init__(config)
+        if hasattr(config, "mm_vision_tower_aux_list"):
+            projector_type = getattr(config, "mm_projector_type", "linear")
+            if projector_type != "sva":
+                raise NotImplementedError("only mm_projector_type='sva' is on the accelerated path "
+                                          "(tdc/cambrian_arch.py:55-161)")
+            C = config.vision_hidden_size
+            H = config.hidden_size
+            self.vision_tower_aux_list = build_vision_tower_aux_list(
+                config, tower_archs=getattr(config, "tdc_tower_archs", None), delay_load=True)
+            self.mm_projector = ParamTree({"0.weight": (H, C * config.num_query_group), "0.bias": (H,),
+                                           "2.weight": (H, H), "2.bias": (H,)})
+            for i, t in enumerate(self.vision_tower_aux_list):
+                setattr(self, "mm_projector_aux_%d" % i, ParamTree({
+                    "0.weight": (C, t.hidden_size), "0.bias": (C,), "2.weight": (C, C), "2.bias": (C,),
+                    "3.weight": (C,), "3.bias": (C,)}))
+            tok = config.mm_vision_tower_aux_token_len_list
+            for g in range(config.num_query_group):
+                r = int(tok[0] ** 0.5) // int(config.query_num_list[g] ** 0.5)
+                setattr(self, "vision_sampler_%d" % g, ParamTree(
+                    sva_spec(C, config.connector_depth, len(self.vision_tower_aux_list), r),
+                    init=lambda n, p: (_randn_init if n.startswith("pos_embed") else _default_init)(n, p)))
+            if not getattr(config, "connector_only", True):
+                raise NotImplementedError("connector_only=False (in-LLM vision samplers) is outside the hot path")
+            self.vision_query = nn.Parameter(torch.randn(config.num_query_group, C), requires_grad=False)
+            self.image_newline = nn.Parameter(torch.randn(H) * 0.02, requires_grad=False)
+            self.frame_seg = nn.Parameter(torch.randn(H), requires_grad=False)
+        self.initialize_compressor(config=config, pretrained_qformer=None,
+                                   context_token_num=getattr(config, "context_token_num", 16))
+        if getattr(config, "audio_input", False):
+            self.audio_proj = ParamTree({"weight": (config.hidden_size, 768), "bias": (config.hidden_size,)})
+        self._tdc_encoder = None
+
+    def get_vision_tower_aux_list(self):
+        return getattr(self, "vision_tower_aux_list", None)
+
+    def get_frame_pos(self, time_range):
+        raise NotImplementedError("frame_pos=True is not used by the released configs (tdc/cambrian_arch.py:183-190)")
+
+    def initialize_vision_modules(self, model_args, fsdp=None):
+        raise NotImplementedError("training-time module initialisation (tdc/cambrian_arch.py:206-401) is out of scope")
+
+    def initialize_audio(self, model_args):
+        """tdc/cambrian_arch.py:451-467: the BEATs encoder itself is not part of this build; audio tokens are passed in
+        as `audios=[{'audio_tokens': [T,50,768]}]`."""
+        if not hasattr(self, "audio_proj"):
+            self.audio_proj = ParamTree({"weight": (self.config.hidden_size, 768), "bias": (self.config.hidden_size,)})
+        return None
+
+    def initialize_compressor(self, config, pretrained_qformer=None, context_token_num=16):
+        """tdc/cambrian_arch.py:469-484 (+ init_Qformer :403-424): bert-base Q-Former with cross-attention to the LLM
+        embedding width every other layer; query_proj / vision_proj."""
+        H = config.hidden_size
+        qc = getattr(config, "tdc_qformer_arch", None) or dict(hidden=768, layers=12, heads=12, ffn=3072, vocab=30522,
+                                                               max_pos=512)
+        self._qformer_arch = dict(qc)
+        self.Qformer = ParamTree(qformer_spec(qc["hidden"], qc["layers"], qc["ffn"], H, qc["vocab"], qc["max_pos"]))
+        self.query_tokens = nn.Parameter(torch.zeros(1, context_token_num, qc["hidden"]).normal_(0, 0.02),
+                                         requires_grad=False)
+        self.vision_proj = ParamTree({"weight": (H, qc["hidden"]), "bias": (H,)})
+        self.query_proj = ParamTree({"weight": (qc["hidden"], H), "bias": (qc["hidden"],)})
+        self.bert_tokenizer = None
+        try:  # the reference loads ./checkpoints/bert-base-uncased (tdc/cambrian_arch.py:405)
+            from transformers import BertTokenizer
+            self.bert_tokenizer = BertTokenizer.from_pretrained("./checkpoints/bert-base-uncased",
+                                                                truncation_side="right")
+        except Exception:
+            self.bert_tokenizer = None
+
+    # ---- HIP engine -------------------------------------------------------------------------------------------
+    def tdc_state_dict(self):
+        """reference-named state dict (without 'model.') of everything on the path, towers included."""
+        sd = {}
+        for k, v in self.state_dict().items():
+            if k.startswith(("mm_projector", "vision_sampler_", "vision_query", "image_newline", "frame_seg",
+                             "Qformer.", "vision_proj", "query_proj", "audio_proj", "query_tokens")):
+                sd[k] = v
+        for i, t in enumerate(self.vision_tower_aux_list):
+            if not t.is_loaded:
+                t.load_model()
+            for k, v in t.vision_tower.state_dict().items():
+                sd["vision_tower_aux_list.%d.vision_tower.%s" % (i, k)] = v
+        return sd
+
+    def tdc_engine(self, device=None, dtype=None, refresh=False):
+        """Build (once) the VideoEncoder from the current parameters: pads / fuses / uploads the weights."""
+        if self._tdc_encoder is None or refresh:
+            cfg = {k: getattr(self.config, k) for k in dir(self.config)
+                   if not k.startswith("_") and isinstance(getattr(self.config, k, None), (int, float, str, bool, list))}
+            device = device or ("cuda:%d" % torch.cuda.current_device())
+            dtype = dtype or (self.dtype if self.dtype in (torch.float16, torch.bfloat16) else torch.float16)
+            towers = self.vision_tower_aux_list
+            self._tdc_encoder = VideoEncoder(self.tdc_state_dict(), cfg, dtype=dtype, device=device,
+                                             siglip_heads=towers[0].heads, dino_heads=towers[1].heads,
+                                             qformer_heads=self._qformer_arch["heads"])
+        return self._tdc_encoder
+
+
+class CambrianMetaForCausalLM(ABC):
+    """tdc/cambrian_arch.py:546-1898."""
+
+    @abstractmethod
+    def get_model(self):
+        pass
+
+    def get_vision_tower_aux_list(self):
+        return self.get_model().get_vision_tower_aux_list()
+
+    # ---- a2 -----------------------------------------------------------------------------------------------------
+    def encode_images(self, image_aux_list, encode_type=None):
+        """tdc/cambrian_arch.py:698-745: run a tower ('dino' -> last entry, 'siglip' -> first, None -> all) in 64-frame
+        batches; returns [B, 576, D] tensors (list for encode_type None)."""
+        eng = self.get_model().tdc_engine()
+        towers = self.get_model().get_vision_tower_aux_list()
+
+        def run(kind, px, D):
+            out = eng.tower(kind, px.to(eng.dev))
+            return out[:, :D].reshape(px.shape[0], -1, D)
+        if encode_type == "dino":
+            return run("dino", image_aux_list[-1], towers[-1].hidden_size)
+        if encode_type == "siglip":
+            return run("siglip", image_aux_list[0], towers[0].hidden_size)
+        return [run(t.kind, px, t.hidden_size) for px, t in zip(image_aux_list, towers)]
+
+    # ---- a1 -----------------------------------------------------------------------------------------------------
+    def _budget_text_len(self, cur_input_ids):
+        pad_id = 128002 if "llama" in getattr(self.get_model().config, "model_type", "") else 151643
+        pos = torch.where(cur_input_ids == pad_id)[-1]
+        return int(pos[0]) if len(pos) > 0 else len(cur_input_ids)
+
+    def _cfg(self):
+        c = self.get_model().config
+        keys = ("context_token_num", "audio_input", "add_static", "tokenizer_model_max_length", "inference_max_length",
+                "max_num_segments", "text_input")
+        d = {k: getattr(c, k) for k in keys if hasattr(c, k)}
+        return d
+
+    def get_max_num_frames(self, cur_input_ids):
+        """tdc/cambrian_arch.py:748-780."""
+        return seg.get_max_num_frames(self._budget_text_len(cur_input_ids), self._cfg())
+
+    def adapt_segment(self, feature_list, split_sizes, new_image_aux_list, window_size=64, threshold=0.9,
+                      max_num_segments=24):
+        """tdc/cambrian_arch.py:783-861 (same 5-tuple).  feature_list: DINO features [sum T, 576, D]."""
+        eng = self.get_model().tdc_engine()
+        feats = torch.split(feature_list, split_sizes, dim=0)
+        a0 = torch.split(new_image_aux_list[0], split_sizes, dim=0)
+        a1 = torch.split(new_image_aux_list[1], split_sizes, dim=0)
+        out_f, out_0, out_1, new_sizes, sel_all, seg_all = [], [], [], [], [], []
+        for i, f in enumerate(feats):
+            T = len(f)
+            if T <= max_num_segments + 1:
+                idx, segi = list(range(T)), list(range(T))
+            else:
+                idx = seg.uniform_indices(T, 224)
+                ff = f[idx] if len(idx) != T else f
+                P, D = ff.shape[1], ff.shape[2]
+                flat = ff.reshape(len(idx) * P, D).contiguous()
+                if D % 8:
+                    raise ValueError("feature width must be a multiple of 8")
+                segi = seg.select_segments(eng.frame_sims(flat.to(eng.dtype), len(idx)), max_num_segments)
+            sel = torch.tensor(idx)
+            out_f.append(f[idx] if len(idx) != T else f)
+            out_0.append(a0[i][idx] if len(idx) != T else a0[i])
+            out_1.append(a1[i][idx] if len(idx) != T else a1[i])
+            new_sizes.append(len(idx))
+            sel_all.append(sel)
+            seg_all.append(torch.tensor(segi))
+        return torch.cat(out_f, 0), new_sizes, [torch.cat(out_0, 0), torch.cat(out_1, 0)], sel_all, seg_all
+
+    # ---- the hot path ---------------------------------------------------------------------------------------------
+    def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels,
+                                             images, image_aux_attention_masks_list=None, image_sizes=None,
+                                             video_indices=None, prompts=None, audios=None):
+        """tdc/cambrian_arch.py:864-1844.  Returns the reference's 10-tuple."""
+        model = self.get_model()
+        towers = model.get_vision_tower_aux_list()
+        if towers is None or images is None or input_ids.shape[1] == 1:
+            return (input_ids, position_ids, attention_mask, past_key_values, None, labels, None, None, None, None)
+        eng = model.tdc_engine()
+        cfgd = self._cfg()
+        K = cfgd.get("context_token_num", 16)
+        H = model.config.hidden_size
+        is_video = type(images[0]) is list or images[0].ndim == 5
+        bsz = input_ids.shape[0]
+        visual = []          # per sample: [n_tokens, H] tensor on the engine device
+        final_size = []
+        for i in range(bsz):
+            if is_video:
+                vid_s, vid_d = images[0][i], images[1][i]
+                if vid_s.ndim == 3:
+                    vid_s, vid_d = vid_s.unsqueeze(0), vid_d.unsqueeze(0)
+            else:
+                vid_s, vid_d = images[0][i:i + 1], images[1][i:i + 1]
+            cur_ids = input_ids[i]
+            if attention_mask is not None:
+                cur_ids = cur_ids[attention_mask[i].bool() | (cur_ids == IMAGE_TOKEN_INDEX)]
+            n_text = int((cur_ids != IMAGE_TOKEN_INDEX).sum())
+            prompt_ids = None
+            if is_video and cfgd.get("text_input", True):
+                prompt = prompts[i] if prompts is not None else None
+                if isinstance(prompt, str):
+                    if model.bert_tokenizer is None:
+                        raise RuntimeError("model.bert_tokenizer is not set (the reference loads "
+                                           "./checkpoints/bert-base-uncased, tdc/cambrian_arch.py:405)")
+                    prompt_ids = model.bert_tokenizer(prompt, padding="longest", truncation=True, max_length=256,
+                                                      return_tensors="pt").input_ids[0].tolist()
+                elif prompt is not None:
+                    prompt_ids = [int(x) for x in prompt]      # pre-tokenised BERT ids
+            audio = None
+            if audios is not None and audios[i] is not None:
+                audio = audios[i].get("audio_tokens") if isinstance(audios[i], dict) else audios[i]
+                if audio is not None:
+                    audio = audio.to(eng.dev)
+            keep = {}
+            if is_video:
+                vis = eng.encode_video(vid_s.to(eng.dev), vid_d.to(eng.dev), tuple(image_sizes[i]),
+                                       budget_text_len=self._budget_text_len(input_ids[i]), n_text_tokens=n_text,
+                                       prompt_ids=prompt_ids, audio=audio, keep=keep)
+            else:
+                # single images: every image is a static frame, no segmentation / Q-Former (cambrian_arch.py:980-983)
+                sig = eng.tower("siglip", vid_s.to(eng.dev))
+                dino = eng.tower("dino", vid_d.to(eng.dev))
+                X, sizes = eng.connector(sig, dino, 1, [tuple(image_sizes[i])], keep)
+                vis = X[:, :H]
+                keep["final_size"] = sizes
+            visual.append(vis)
+            final_size.extend(keep["final_size"])
+        # ---- a21: splice text embeddings and visual tokens, truncate, pad (cambrian_arch.py:1425-1495, :1712-1844)
+        _labels, _position_ids, _attention_mask = labels, position_ids, attention_mask
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids, dtype=torch.bool)
+        else:
+            attention_mask = attention_mask.bool()
+        if position_ids is None:
+            position_ids = torch.arange(0, input_ids.shape[1], dtype=torch.long, device=input_ids.device)
+        if labels is None:
+            labels = torch.full_like(input_ids, IGNORE_INDEX)
+        attention_mask = attention_mask | (input_ids == IMAGE_TOKEN_INDEX)
+        embed = model.embed_tokens
+        new_embeds, new_labels = [], []
+        for i in range(bsz):
+            ids = input_ids[i][attention_mask[i]]
+            lab = labels[i][attention_mask[i]]
+            img_pos = torch.where(ids == IMAGE_TOKEN_INDEX)[0].tolist()
+            vis = visual[i]
+            if not img_pos:
+                new_embeds.append(torch.cat([embed(ids), vis[0:0].to(embed.weight.dtype)], 0))
+                new_labels.append(lab)
+                continue
+            if len(img_pos) != 1:
+                raise NotImplementedError("one <image> token per sample (one video / image per prompt)")
+            p = img_pos[0]
+            text = embed(torch.cat([ids[:p], ids[p + 1:]]))
+            vis = vis.to(text.dtype).to(text.device)
+            new_embeds.append(torch.cat([text[:p], vis, text[p:]], 0))
+            new_labels.append(torch.cat([lab[:p], torch.full((vis.shape[0],), IGNORE_INDEX, device=lab.device,
+                                                             dtype=lab.dtype), lab[p + 1:]]))
+        mx = getattr(self.config, "tokenizer_model_max_length", None)
+        if mx is not None:
+            new_embeds = [x[:mx] for x in new_embeds]
+            new_labels = [x[:mx] for x in new_labels]
+        max_len = max(x.shape[0] for x in new_embeds)
+        left = getattr(self.config, "tokenizer_padding_side", "right") == "left"
+        emb_pad = []
+        lab_pad = torch.full((bsz, max_len), IGNORE_INDEX, dtype=new_labels[0].dtype, device=new_labels[0].device)
+        att = torch.zeros((bsz, max_len), dtype=attention_mask.dtype, device=attention_mask.device)
+        pos = torch.zeros((bsz, max_len), dtype=position_ids.dtype, device=position_ids.device)
+        for i, (e, l) in enumerate(zip(new_embeds, new_labels)):
+            n = e.shape[0]
+            z = torch.zeros((max_len - n, e.shape[1]), dtype=e.dtype, device=e.device)
+            emb_pad.append(torch.cat((z, e), 0) if left else torch.cat((e, z), 0))
+            if n > 0:
+                sl = slice(max_len - n, max_len) if left else slice(0, n)
+                lab_pad[i, sl] = l
+                att[i, sl] = True
+                pos[i, sl] = torch.arange(0, n, dtype=pos.dtype, device=pos.device)
+        new_input_embeds = torch.stack(emb_pad, 0)
+        new_labels_out = None if _labels is None else lab_pad
+        att_out = None if _attention_mask is None else att.to(dtype=_attention_mask.dtype)
+        pos_out = None if _position_ids is None else pos
+        return (None, pos_out, att_out, past_key_values, new_input_embeds, new_labels_out, None, None, final_size, None)
+
+    def initialize_vision_tokenizer(self, model_args, tokenizer):
+        raise NotImplementedError("tokenizer surgery for training (tdc/cambrian_arch.py:1846-1898) is out of scope")

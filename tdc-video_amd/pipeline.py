@@ -39,6 +39,7 @@ class VideoEncoder:
         self.side = int(round(cfg.get("query_num_list", [144])[0] ** 0.5))
         self._tables = {}
         self.K = cfg.get("context_token_num", 16)
+        self.H = cfg["hidden_size"]
 
     # ------------------------------------------------------------------------------------------------ towers
     def _bil(self, n_in, n_out):
@@ -94,10 +95,14 @@ class VideoEncoder:
         return ops.resample_tokens(src, B, t.has_cls, gh, out_grid, D, dt, self._bil(gh, out_grid))
 
     # ------------------------------------------------------------------------------------------------ a5
-    def frame_sims(self, dino_feat, T):
-        """adjacent-frame cosine similarity of the DINO features -> python list of T-1 floats (one D2H copy)."""
+    def sims_tensor(self, dino_feat, T):
+        """adjacent-frame cosine similarity of the DINO features -> fp32 device tensor [T-1]."""
         n = dino_feat.shape[0] // T * dino_feat.shape[1]
-        return ops.frame_cossim(dino_feat, T, n).tolist()
+        return ops.frame_cossim(dino_feat, T, n)
+
+    def frame_sims(self, dino_feat, T):
+        """same as a python list (one D2H copy: the segmentation is host logic)."""
+        return self.sims_tensor(dino_feat, T).tolist()
 
     # ------------------------------------------------------------------------------------------------ a6-a10
     def aux_project(self, feat, i):
@@ -231,91 +236,120 @@ class VideoEncoder:
                               y_map=tmap)
         return h16, S
 
+    def with_audio(self, X, T, N, audio):
+        """a20: frames become [visual N | audio_proj(audio) Na] rows (tdc/cambrian_arch.py:1611-1614)."""
+        c, dt, dev = self.c, self.dtype, self.dev
+        if audio is None:
+            return X, N
+        Hp = X.shape[1]
+        Na = audio.shape[1]
+        A16 = torch.zeros(T * Na, pad64(audio.shape[2]), device=dev, dtype=dt)
+        A16[:, : audio.shape[2]] = audio.reshape(T * Na, -1).to(dt)
+        Xf = torch.empty(T * (N + Na), Hp, device=dev, dtype=dt)
+        Xf.view(T, N + Na, Hp)[:, :N].copy_(X.view(T, N, Hp))          # visual rows (device copy)
+        ops.gemm(A16, c.audio_proj.w, c.audio_proj.b, out=Xf, c_map=(Na, N + Na, N, 1))   # audio rows
+        return Xf, N + Na
+
+    def make_queries(self, Xf, N, Nf, key_rows):
+        """a12: adaptive-avg-pool the (visual part of the) key frames N -> K tokens and apply query_proj.
+        key_rows: frame indices into Xf.  Returns [len(key_rows)*K, Dq_pad]."""
+        keys = torch.tensor(key_rows, dtype=torch.int32, device=self.dev)
+        pooled = ops.adaptive_pool_tokens(Xf, N, self.K, len(key_rows), keys, frame_rows=Nf)
+        return ops.gemm(pooled, self.c.query_proj.w, self.c.query_proj.b)
+
+    def compress_frames(self, Xf, Nf, frame_rows, qtable, qsrc, prompt_ids, keep=None):
+        """a13-a18 for the frames `frame_rows` of Xf: Q-Former against queries qtable[qsrc[f]] -> [F*K, >=H] unit rows."""
+        c, dev = self.c, self.dev
+        K, H = self.K, c.H
+        F = len(frame_rows)
+        Hp = Xf.shape[1]
+        enc_idx = torch.tensor([(0, f * Nf + i) for f in frame_rows for i in range(Nf)], dtype=torch.int32, device=dev)
+        enc = ops.gather_rows([Xf], enc_idx, F * Nf, Hp)
+        qs = torch.tensor(qsrc, dtype=torch.int32, device=dev)
+        h16, S = self.qformer(enc, F, Nf, qtable, qs, prompt_ids)
+        comp = ops.gemm(h16, c.vision_proj.w, c.vision_proj.b, M=F * K, a_map=(K, S, 0, 1))
+        ops.l2_normalize(comp, F * K, H)
+        if keep is not None:
+            keep.update(compressed=comp, last_hidden=h16, S=S)
+        return comp
+
+    def query_width(self):
+        return pad64(self.c.qformer.dim)
+
+    def emit(self, Xf, comp, pairs):
+        """a19: one gather over (frame tokens | context tokens | frame_seg) -> [len(pairs), H]."""
+        idx = torch.tensor(pairs, dtype=torch.int32, device=self.dev).contiguous()
+        tables = [Xf, comp if comp is not None else self.c.frame_seg, self.c.frame_seg]
+        return ops.gather_rows(tables, idx, len(pairs), self.c.H)
+
     def compress(self, X, T, N, seg_indices, prompt_ids, max_visual_len, audio=None, keep=None):
         """X [T*N, Hp] -> emitted visual tokens [n, H] (tdc/cambrian_arch.py:1520-1709)."""
-        c, dt, dev = self.c, self.dtype, self.dev
-        H, Hp = c.H, pad64(c.H)
-        K = self.K
-        Na = 0
-        Xf = X
-        if audio is not None:
-            # a20: frames become [visual N | audio_proj(audio) 50] (cambrian_arch.py:1611-1614)
-            Na = audio.shape[1]
-            A16 = torch.zeros(T * Na, pad64(audio.shape[2]), device=dev, dtype=dt)
-            A16[:, : audio.shape[2]] = audio.reshape(T * Na, -1).to(dt)
-            Xf = torch.empty(T * (N + Na), Hp, device=dev, dtype=dt)
-            Xf.view(T, N + Na, Hp)[:, :N].copy_(X.view(T, N, Hp))          # visual rows (device copy)
-            ops.gemm(A16, c.audio_proj.w, c.audio_proj.b, out=Xf, c_map=(Na, N + Na, N, 1))   # audio rows
-        Nf = N + Na
-        plan = seg.emit_plan(T, Nf, K, seg_indices, max_visual_len)
-        comp_frames = plan["comp_frames"]
-        F = len(comp_frames)
-        comp = None
-        if F > 0:
-            nC = len(plan["key_frames"])
-            keys = torch.tensor(plan["key_frames"], dtype=torch.int32, device=dev)
-            pooled = ops.adaptive_pool_tokens(Xf, N, K, nC, keys, frame_rows=Nf)        # visual-only key frame
-            query = ops.gemm(pooled, c.query_proj.w, c.query_proj.b)                    # [nC*K, Dq_pad]
-            enc_idx = torch.tensor([(0, f * Nf + i) for f in comp_frames for i in range(Nf)], dtype=torch.int32,
-                                   device=dev)
-            enc = ops.gather_rows([Xf], enc_idx, F * Nf, Hp)
-            qsrc = torch.tensor(plan["comp_chunk"], dtype=torch.int32, device=dev)
-            h16, S = self.qformer(enc, F, Nf, query, qsrc, prompt_ids)
-            comp = ops.gemm(h16, c.vision_proj.w, c.vision_proj.b, M=F * K, a_map=(K, S, 0, 1))
-            ops.l2_normalize(comp, F * K, H)
-            if keep is not None:
-                keep.update(compressed=comp, last_hidden=h16, S=S)
-        # emission: one gather over (static frame tokens | context tokens | frame_seg)
-        tab = {"f": 0, "c": 1, "s": 2}
-        src = []
-        for e in plan["src"]:
-            if e[0] == "f":
-                src.append((0, e[1] * Nf + e[2]))
-            elif e[0] == "c":
-                src.append((1, e[1] * K + e[2]))
-            else:
-                src.append((2, 0))
-        idx = torch.tensor(src, dtype=torch.int32, device=dev).contiguous()
-        tables = [Xf, comp if comp is not None else c.frame_seg, c.frame_seg]
-        out = ops.gather_rows(tables, idx, len(src), H)
-        if keep is not None:
-            keep["plan"] = plan
-        return out
+        return compress_with(self, X, T, N, seg_indices, prompt_ids, max_visual_len, audio, keep)
 
     # ------------------------------------------------------------------------------------------------ top level
     def encode_video(self, px_siglip, px_dino, image_size, budget_text_len, n_text_tokens, prompt_ids, audio=None,
                      frame_cap=224, keep=None):
         """One video: pixels -> emitted visual tokens [n, H] (S0-S10).  `budget_text_len` is the text length used by
         get_max_num_frames (cambrian_arch.py:753-759), `n_text_tokens` the non-image token count (:1499-1505)."""
-        cfg = self.cfg
-        T0 = px_siglip.shape[0]
-        idx = seg.uniform_indices(T0, min(seg.get_max_num_frames(budget_text_len, cfg), frame_cap))     # a1
-        if len(idx) != T0:
-            sel = torch.tensor(idx, device=px_siglip.device)
-            px_siglip, px_dino = px_siglip[sel], px_dino[sel]
-        T = len(idx)
-        dino = self.tower("dino", px_dino)                                                              # a4
-        mns = cfg.get("max_num_segments", 24)
-        if T <= mns + 1:                                                                                 # a5
-            sel2, seg_idx = list(range(T)), list(range(T))
+        return encode_video_with(self, px_siglip, px_dino, image_size, budget_text_len, n_text_tokens, prompt_ids,
+                                 audio, frame_cap, keep)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Orchestration over an "engine" (VideoEncoder on GPUs; the gloo tests of dist.py plug in a CPU test double that
+# implements tower / sims_tensor / connector / with_audio / make_queries / compress_frames / emit / query_width).
+def compress_with(e, X, T, N, seg_indices, prompt_ids, max_visual_len, audio=None, keep=None):
+    K = e.K
+    Xf, Nf = e.with_audio(X, T, N, audio)
+    plan = seg.emit_plan(T, Nf, K, seg_indices, max_visual_len)
+    comp = None
+    if plan["comp_frames"]:
+        qtable = e.make_queries(Xf, N, Nf, plan["key_frames"])
+        comp = e.compress_frames(Xf, Nf, plan["comp_frames"], qtable, plan["comp_chunk"], prompt_ids, keep)
+    pairs = []
+    for en in plan["src"]:
+        if en[0] == "f":
+            pairs.append((0, en[1] * Nf + en[2]))
+        elif en[0] == "c":
+            pairs.append((1, en[1] * K + en[2]))
         else:
-            sel2 = seg.uniform_indices(T, frame_cap)
-            if len(sel2) != T:
-                s2 = torch.tensor(sel2, device=px_siglip.device)
-                P = dino.shape[0] // T
-                dino = dino.view(T, P, -1)[s2].reshape(len(sel2) * P, -1)
-                px_siglip = px_siglip[s2]
-                T = len(sel2)
-            sims = self.frame_sims(dino, T)
-            seg_idx = seg.select_segments(sims, mns)
-        sig = self.tower("siglip", px_siglip)                                                           # a3
-        sizes = [tuple(image_size)] * T
-        X, final_size = self.connector(sig, dino, T, sizes, keep)                                       # a6-a10
-        N = X.shape[0] // T
-        max_visual_len = cfg["tokenizer_model_max_length"] - cfg.get("inference_max_length", 16) - n_text_tokens
-        pid = prompt_ids if cfg.get("text_input", True) else None
-        vis = self.compress(X, T, N, seg_idx, pid, max_visual_len, audio, keep)                         # a11-a19
-        if keep is not None:
-            keep.update(frame_indices=idx, selected=sel2, seg_indices=seg_idx, siglip_feat=sig, dino_feat=dino,
-                        final_size=final_size, X=X)
-        return vis
+            pairs.append((2, 0))
+    if keep is not None:
+        keep["plan"] = plan
+    return e.emit(Xf, comp, pairs)
+
+
+def encode_video_with(e, px_siglip, px_dino, image_size, budget_text_len, n_text_tokens, prompt_ids, audio=None,
+                      frame_cap=224, keep=None):
+    cfg = e.cfg
+    T0 = px_siglip.shape[0]
+    idx = seg.uniform_indices(T0, min(seg.get_max_num_frames(budget_text_len, cfg), frame_cap))     # a1
+    if len(idx) != T0:
+        sel = torch.tensor(idx, device=px_siglip.device)
+        px_siglip, px_dino = px_siglip[sel], px_dino[sel]
+    T = len(idx)
+    dino = e.tower("dino", px_dino)                                                                 # a4
+    mns = cfg.get("max_num_segments", 24)
+    if T <= mns + 1:                                                                                # a5
+        sel2, seg_idx = list(range(T)), list(range(T))
+    else:
+        sel2 = seg.uniform_indices(T, frame_cap)
+        if len(sel2) != T:
+            s2 = torch.tensor(sel2, device=px_siglip.device)
+            P = dino.shape[0] // T
+            dino = dino.view(T, P, -1)[s2].reshape(len(sel2) * P, -1)
+            px_siglip = px_siglip[s2]
+            T = len(sel2)
+        sims = e.sims_tensor(dino, T).tolist()
+        seg_idx = seg.select_segments(sims, mns)
+    sig = e.tower("siglip", px_siglip)                                                              # a3
+    sizes = [tuple(image_size)] * T
+    X, final_size = e.connector(sig, dino, T, sizes, keep)                                          # a6-a10
+    N = X.shape[0] // T
+    max_visual_len = cfg["tokenizer_model_max_length"] - cfg.get("inference_max_length", 16) - n_text_tokens
+    pid = prompt_ids if cfg.get("text_input", True) else None
+    vis = compress_with(e, X, T, N, seg_idx, pid, max_visual_len, audio, keep)                      # a11-a19
+    if keep is not None:
+        keep.update(frame_indices=idx, selected=sel2, seg_indices=seg_idx, siglip_feat=sig, dino_feat=dino,
+                    final_size=final_size, X=X)
+    return vis

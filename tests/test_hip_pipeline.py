@@ -222,3 +222,43 @@ def test_full_pipeline_vs_golden(name, dtype):
         want = torch.stack(list(ref_rows.values()))
         err = (got - want).abs().max().item()
         assert err < (1e-3 if dtype == torch.float16 else 8e-3), err
+
+
+@pytest.mark.parametrize("name", ["pipeline_T40.npz", "pipeline_T10_land.npz"])
+def test_mixin_boundary_vs_golden(name):
+    """The drop-in boundary itself: CambrianMetaForCausalLM.prepare_inputs_labels_for_multimodal -> reference 10-tuple."""
+    from test_host_logic import build_stub_lm, tiny_config
+    W, o = load_fixture(name)
+    lm = build_stub_lm(tiny_config())
+    m = lm.model
+    sd = {k: v for k, v in W.items() if not k.startswith("vision_tower_aux_list")}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    for i, t in enumerate(m.vision_tower_aux_list):
+        pre = "vision_tower_aux_list.%d.vision_tower." % i
+        t.load_model(state_dict={k[len(pre):]: v for k, v in W.items() if k.startswith(pre)})
+    with torch.no_grad():
+        ids_used = [int(i) for i in o["used_embed_ids"]]
+        m.embed_tokens.weight[ids_used] = torch.from_numpy(o["used_embed_rows"])
+    vid = torch.from_numpy(synth.video_from_basis(o["video_basis"], o["video_coef"]))
+    images = [vid.unsqueeze(0), (vid + 0.01).unsqueeze(0)]
+    ids = torch.from_numpy(o["input_ids"])
+    size = tuple(int(v) for v in o["image_size"])
+    out = lm.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, images, image_sizes=[size],
+                                                  video_indices=[None], prompts=[[int(i) for i in o["prompt_ids"]]],
+                                                  audios=[None])
+    assert len(out) == 10 and out[0] is None and out[1] is None and out[2] is None and out[5] is None
+    emb = out[4]
+    ref = torch.from_numpy(o["out_inputs_embeds"])
+    assert emb.shape == ref.shape
+    assert rel(emb, ref) < stage_tol(torch.float16)
+    assert [list(s) for s in out[8]] == o["out_final_size"].tolist()
+    # with labels / attention mask / position ids given, the padded companions come back
+    am = torch.ones_like(ids)
+    out2 = lm.prepare_inputs_labels_for_multimodal(ids, torch.arange(ids.shape[1])[None], am, None, ids.clone(), images,
+                                                   image_sizes=[size], video_indices=[None],
+                                                   prompts=[[int(i) for i in o["prompt_ids"]]], audios=[None])
+    S = ref.shape[1]
+    assert out2[1].shape == (1, S) and out2[2].shape == (1, S) and out2[5].shape == (1, S)
+    assert int((out2[5] == -100).sum()) == S - (ids.shape[1] - 1)
+    assert torch.equal(out2[1][0], torch.arange(S))
