@@ -94,6 +94,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: its bundled HIP runtime (libamdhip64) must be the one this process uses; loading ours first would
+    # pull /opt/rocm's copy in and the two runtimes do not share devices/streams (hipErrorNoDevice at first launch).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise TdcHipError("libtdc_hip.so not found at %s: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(the product path has no CPU fallback)" % LIB_PATH)

@@ -262,3 +262,26 @@ def test_mixin_boundary_vs_golden(name):
     assert out2[1].shape == (1, S) and out2[2].shape == (1, S) and out2[5].shape == (1, S)
     assert int((out2[5] == -100).sum()) == S - (ids.shape[1] - 1)
     assert torch.equal(out2[1][0], torch.arange(S))
+
+
+def test_sharded_world1_nccl_equals_serial():
+    """dist.ShardedVideoEncoder over RCCL with a single rank must equal the serial path bit for bit."""
+    import os
+    import torch.distributed as dist
+    from tdc_video_amd.dist import ShardedVideoEncoder
+    W, o = load_fixture("pipeline_T40.npz")
+    cfg = pipeline_cfg(o)
+    enc = make_encoder(W, cfg, torch.float16)
+    vid = torch.from_numpy(synth.video_from_basis(o["video_basis"], o["video_coef"])).cuda()
+    ids = torch.from_numpy(o["input_ids"])[0]
+    size = tuple(int(v) for v in o["image_size"])
+    pid = [int(i) for i in o["prompt_ids"]]
+    want = enc.encode_video(vid, vid + 0.01, size, len(ids), len(ids) - 1, pid)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        got = ShardedVideoEncoder(enc, 0, 1).encode_video(vid, vid + 0.01, vid.shape[0], size, len(ids) - 1, pid)
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(got, want)
