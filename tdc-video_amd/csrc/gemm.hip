@@ -16,6 +16,7 @@
 #include "common.h"
 #include "../../include/tdc_hip.h"
 #include <stdio.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -36,6 +37,94 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     int q = nwg >> 3, r = nwg & 7, x = bid & 7;
     int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
     return base + (bid >> 3);
+}
+
+// ---- epilogue -------------------------------------------------------------------------------------------------------
+// Each lane holds, per (i, j) accumulator tile, 4 consecutive output columns n..n+3 of ONE output row m.  The epilogue
+// is specialised at compile time on (activation, residual kind, output type): the run-time flags select one of the
+// branch-free instantiations once per kernel, so bias vectors are loaded once per column tile and the residual
+// loads / stores of a row issue back to back instead of waiting on each other.
+template <class T, int ACT, int RES, bool OUTF32>
+__device__ __forceinline__ void epi_store(const GemmArgs& p, f32x4 v, f32x4 bias, long long crow, long long rrow,
+                                          int n) {
+    v += bias;
+    if (ACT == TDC_ACT_GELU_ERF) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+    } else if (ACT == TDC_ACT_GELU_TANH) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+    } else if (ACT == TDC_ACT_SWIGLU) {
+        // columns are interleaved (x1_j, x2_j): two outputs per lane at column n/2
+        const float o0 = silu(v[0]) * v[1], o1 = silu(v[2]) * v[3];
+        const int nc = n >> 1;
+        if (OUTF32) {
+            float* c = (float*)p.C + crow * p.ldc + nc;
+            c[0] = o0; c[1] = o1;
+        } else {
+            typedef __attribute__((ext_vector_type(2))) T v2;
+            v2 o; o[0] = (T)o0; o[1] = (T)o1;
+            *(v2*)((T*)p.C + crow * p.ldc + nc) = o;
+        }
+        return;
+    }
+    if (RES == 1) {
+        v += *(const f32x4*)((const float*)p.res + rrow * p.ldres + n);
+    } else if (RES == 2) {
+        typename VecOf<T>::v4 r = *(const typename VecOf<T>::v4*)((const T*)p.res + rrow * p.ldres + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+    }
+    if (OUTF32) {
+        *(f32x4*)((float*)p.C + crow * p.ldc + n) = v;
+    } else {
+        typename VecOf<T>::v4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (T)v[e];
+        *(typename VecOf<T>::v4*)((T*)p.C + crow * p.ldc + n) = o;
+    }
+}
+
+template <class T, int MI, int NJ, int ACT, int RES, bool OUTF32>
+__device__ __forceinline__ void epi_tile(const GemmArgs& p, f32x4 (&acc)[MI][NJ], int mbase, int nbase, int fr,
+                                         int g) {
+    f32x4 bias[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = nbase + j * 16 + g * 4;
+        bias[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (p.bias && n < p.N) bias[j] = *(const f32x4*)(p.bias + n);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = mbase + i * 16 + fr;
+        if (m < p.M) {
+            const long long crow = p.cm(m);
+            const long long rrow = RES ? p.rm(m) : 0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = nbase + j * 16 + g * 4;
+                if (n < p.N) epi_store<T, ACT, RES, OUTF32>(p, acc[i][j], bias[j], crow, rrow, n);
+            }
+        }
+    }
+}
+
+template <class T, int MI, int NJ>
+__device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[MI][NJ], int mbase, int nbase, int fr, int g) {
+    const int res = p.res ? (p.res_f32 ? 1 : 2) : 0;
+    if (p.act == TDC_ACT_GELU_ERF) epi_tile<T, MI, NJ, TDC_ACT_GELU_ERF, 0, false>(p, acc, mbase, nbase, fr, g);
+    else if (p.act == TDC_ACT_GELU_TANH) epi_tile<T, MI, NJ, TDC_ACT_GELU_TANH, 0, false>(p, acc, mbase, nbase, fr, g);
+    else if (p.act == TDC_ACT_SWIGLU) epi_tile<T, MI, NJ, TDC_ACT_SWIGLU, 0, false>(p, acc, mbase, nbase, fr, g);
+    else if (p.out_f32) {
+        if (res == 1) epi_tile<T, MI, NJ, 0, 1, true>(p, acc, mbase, nbase, fr, g);
+        else if (res == 2) epi_tile<T, MI, NJ, 0, 2, true>(p, acc, mbase, nbase, fr, g);
+        else epi_tile<T, MI, NJ, 0, 0, true>(p, acc, mbase, nbase, fr, g);
+    } else {
+        if (res == 1) epi_tile<T, MI, NJ, 0, 1, false>(p, acc, mbase, nbase, fr, g);
+        else if (res == 2) epi_tile<T, MI, NJ, 0, 2, false>(p, acc, mbase, nbase, fr, g);
+        else epi_tile<T, MI, NJ, 0, 0, false>(p, acc, mbase, nbase, fr, g);
+    }
 }
 
 template <class T>
@@ -115,61 +204,193 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         __syncthreads();  // drains the glds of tile kt+1 (vmcnt(0)) and fences the reads of buffer `cur`
     }
 
-    // ---- epilogue: lane holds C[m = ... + fr][n = ... + 4g .. 4g+3] for each (i, j)
+    // ---- epilogue: lane holds C[m = m0 + wm*64 + 16 i + fr][n = n0 + wn*64 + 16 j + 4g .. +3]
+    epilogue<T, 4, 4>(p, acc, m0 + wm * 64, n0 + wn_ * 64, fr, g);
+}
+
+// ======================================================================================================================
+// 256x256x64 tile, 8 waves (2 M x 4 N, 128x64 per wave), 128 KiB LDS, "8-phase" schedule (cdna_hip_programming.md
+// T3+T4): every K tile is 4 phases of 16 MFMAs (one 64x32 quadrant of the wave's tile x K=64); each phase stages ONE
+// 16-KiB half-tile with global_load_lds, and the loads stay in flight ACROSS the raw s_barriers: a counted
+// s_waitcnt vmcnt(6) once per K tile (3 half-tiles in flight), never vmcnt(0) in the steady state.
+//
+// LDS: buf[2] x {A-half0, A-half1, W-half0, W-half1} x 16 KiB.  Half h of A holds rows {wm*128 + h*64 + 0..63} of both
+// wave rows wm, half h of W the columns {wn*64 + h*32 + 0..31} of all four wave columns, so quadrant (a_h, b_h') of
+// every wave needs exactly one A half and one W half.  Quadrant order (a0,b0) (a0,b1) (a1,b1) (a1,b0): one new operand
+// sub-block per phase, b0 stays in registers.  Staging order A0 B0 B1 A1; tile t+2's A0/B0/B1 are issued during tile
+// t's phases 2/3/4 into the regions tile t has finished reading one phase earlier (all waves have passed a barrier
+// after their lgkmcnt-retired reads), tile t+1's A1 during phase 1.
+constexpr int T2_HALF = 128 * 64 * 2;         // 16 KiB
+constexpr int T2_BUF = 4 * T2_HALF;           // A0 A1 W0 W1
+constexpr int T2_LDS = 2 * T2_BUF;            // 128 KiB
+
+template <class T>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
+    typedef typename VecOf<T>::v8 v8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int id = xcd_remap(blockIdx.x, nwg);
+    const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    // ---- staging sources: per half 2 glds per thread; instruction (wave*2 + j) covers half rows 8*(wave*2+j) .. +7
+    const int srow = lane >> 3;
+    const int schunk = (lane & 7) ^ srow;
+    const char* a_src[2][2];
+    const char* w_src[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = (wave * 2 + j) * 8 + srow;                       // row within the half (0..127)
+            int am = m0 + (r >> 6) * 128 + h * 64 + (r & 63);
+            int wn = n0 + (r >> 5) * 64 + h * 32 + (r & 31);
+            if (am > p.M - 1) am = p.M - 1;
+            if (wn > p.N - 1) wn = p.N - 1;
+            a_src[h][j] = (const char*)p.A + (p.am(am) * (long long)p.lda + schunk * 8) * 2;
+            w_src[h][j] = (const char*)p.W + ((long long)wn * p.ldw + schunk * 8) * 2;
+        }
+    const int lds_stage = wave * 2 * 1024;
+    auto stage_a = [&](int buf, int h, int kt) {
+        char* dst = smem + buf * T2_BUF + h * T2_HALF + lds_stage;
+        const long long koff = (long long)kt * 128;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[h][0] + koff), LDS_PTR(dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[h][1] + koff), LDS_PTR(dst + 1024), 16, 0, 0);
+    };
+    auto stage_w = [&](int buf, int h, int kt) {
+        char* dst = smem + buf * T2_BUF + (2 + h) * T2_HALF + lds_stage;
+        const long long koff = (long long)kt * 128;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(w_src[h][0] + koff), LDS_PTR(dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(w_src[h][1] + koff), LDS_PTR(dst + 1024), 16, 0, 0);
+    };
+
+    // ---- fragment read offsets inside a half
+    const int wm = wave >> 2, wn_ = wave & 3;
+    const int fr = lane & 15, g = lane >> 4;
+    int a_off[4], w_off[2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + fr;
-        if (m >= p.M) continue;
-        const long long crow = p.cm(m);
-        const long long rrow = p.res ? p.rm(m) : 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn_ * 64 + j * 16 + g * 4;
-            if (n >= p.N) continue;
-            f32x4 v = acc[i][j];
-            if (p.bias) {
-                f32x4 b = *(const f32x4*)(p.bias + n);
-                v += b;
-            }
-            if (p.act == TDC_ACT_GELU_ERF) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-            } else if (p.act == TDC_ACT_GELU_TANH) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
-            } else if (p.act == TDC_ACT_SWIGLU) {
-                // columns are interleaved (x1_j, x2_j): two outputs per lane at column n/2
-                float o0 = silu(v[0]) * v[1], o1 = silu(v[2]) * v[3];
-                const int nc = n >> 1;
-                if (p.out_f32) {
-                    float* c = (float*)p.C + crow * p.ldc + nc;
-                    c[0] = o0; c[1] = o1;
-                } else {
-                    T* c = (T*)p.C + crow * p.ldc + nc;
-                    c[0] = (T)o0; c[1] = (T)o1;
-                }
-                continue;
-            }
-            if (p.res) {
-                if (p.res_f32) {
-                    f32x4 r = *(const f32x4*)((const float*)p.res + rrow * p.ldres + n);
-                    v += r;
-                } else {
-                    typename VecOf<T>::v4 r = *(const typename VecOf<T>::v4*)((const T*)p.res + rrow * p.ldres + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
-                }
-            }
-            if (p.out_f32) {
-                *(f32x4*)((float*)p.C + crow * p.ldc + n) = v;
-            } else {
-                typename VecOf<T>::v4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (T)v[e];
-                *(typename VecOf<T>::v4*)((T*)p.C + crow * p.ldc + n) = o;
-            }
-        }
+        const int r = wm * 64 + i * 16 + fr;
+        a_off[i] = r * 128 + ((g ^ (r & 7)) << 4);
     }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = wn_ * 32 + j * 16 + fr;
+        w_off[j] = r * 128 + ((g ^ (r & 7)) << 4);
+    }
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    v8 fa[4][2], fb0[2][2], fb1[2][2];
+
+    const int nk = p.K / 64;
+#define T2_BARRIER() __builtin_amdgcn_s_barrier()
+    // end of a load segment: retire this wave's LDS reads BEFORE the barrier (so that a later stage by any wave, incl.
+    // the other, staggered, wave group, can never overwrite bytes still being read), then pin the MFMA cluster below it
+#define T2_END_LOADS()                                          \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          \
+    __builtin_amdgcn_s_barrier();                               \
+    __builtin_amdgcn_sched_barrier(0)
+#define T2_LOAD_A(buf, h)                                                          \
+    {                                                                               \
+        const char* base = smem + (buf) * T2_BUF + (h) * T2_HALF;                   \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                             \
+            fa[i][0] = *(const v8*)(base + a_off[i]);                               \
+            fa[i][1] = *(const v8*)(base + (a_off[i] ^ 64));                        \
+        }                                                                           \
+    }
+#define T2_LOAD_B(dst, buf, h)                                                      \
+    {                                                                               \
+        const char* base = smem + (buf) * T2_BUF + (2 + (h)) * T2_HALF;             \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                             \
+            dst[j][0] = *(const v8*)(base + w_off[j]);                              \
+            dst[j][1] = *(const v8*)(base + (w_off[j] ^ 64));                       \
+        }                                                                           \
+    }
+#define T2_MMA(MI0, NJ0, fbx)                                                       \
+    {                                                                               \
+        __builtin_amdgcn_s_setprio(1);                                              \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                            \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                               \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                               \
+            acc[(MI0) + i][(NJ0) + j] = mfma16(fbx[j][ks], fa[i][ks], acc[(MI0) + i][(NJ0) + j]); \
+        __builtin_amdgcn_s_setprio(0);                                              \
+    }
+
+    // ---- prologue: tile 0 complete + tile 1's A0 B0 B1
+    stage_a(0, 0, 0); stage_w(0, 0, 0); stage_w(0, 1, 0); stage_a(0, 1, 0);
+    if (nk > 1) {
+        stage_a(1, 0, 1); stage_w(1, 0, 1); stage_w(1, 1, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    T2_BARRIER();
+    // stagger: waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in its MFMA cluster while its
+    // partner is in its LDS-read / staging segment (MI355X_MICROARCH.md "Two waves per SIMD")
+    if (wave >= 4) T2_BARRIER();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1, nxt = cur ^ 1;
+        // ---- phase 1: quadrant (a0, b0)
+        T2_LOAD_B(fb0, cur, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        T2_LOAD_A(cur, 0);
+        if (kt + 1 < nk) stage_a(nxt, 1, kt + 1);
+        T2_END_LOADS();
+        T2_MMA(0, 0, fb0);
+        T2_BARRIER();
+        // ---- phase 2: quadrant (a0, b1)
+        T2_LOAD_B(fb1, cur, 1);
+        if (kt + 2 < nk) stage_a(cur, 0, kt + 2);
+        T2_END_LOADS();
+        T2_MMA(0, 2, fb1);
+        T2_BARRIER();
+        // ---- phase 3: quadrant (a1, b1)
+        T2_LOAD_A(cur, 1);
+        if (kt + 2 < nk) stage_w(cur, 0, kt + 2);
+        T2_END_LOADS();
+        T2_MMA(4, 2, fb1);
+        T2_BARRIER();
+        // ---- phase 4: quadrant (a1, b0); retire tile kt+1 (3 half-tiles of tile kt+2 may stay in flight)
+        if (kt + 2 < nk) {
+            stage_w(cur, 1, kt + 2);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        T2_BARRIER();
+        __builtin_amdgcn_sched_barrier(0);
+        T2_MMA(4, 0, fb0);
+        T2_BARRIER();
+    }
+    if (wave < 4) T2_BARRIER();   // matches the stagger barrier of waves 4-7
+#undef T2_END_LOADS
+#undef T2_BARRIER
+#undef T2_LOAD_A
+#undef T2_LOAD_B
+#undef T2_MMA
+
+    // ---- epilogue: lane holds C[m = m0 + wm*128 + 16 i + fr][n = n0 + wn*64 + 16 j + 4g .. +3]
+    epilogue<T, 8, 4>(p, acc, m0 + wm * 128, n0 + wn_ * 64, fr, g);
+}
+
+// kernel choice: the 256^2 8-phase kernel needs enough tiles to fill the 256 CUs; TDC_GEMM_FORCE=128|256 overrides
+inline bool use_256(int M, int N, int K) {
+    static int force = -1;
+    if (force < 0) {
+        const char* e = getenv("TDC_GEMM_FORCE");
+        force = e ? atoi(e) : 0;
+    }
+    if (force == 128) return false;
+    if (force == 256) return true;
+    const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256);
+    return t256 >= 192 && K >= 128;
 }
 
 template <class T>
@@ -182,6 +403,18 @@ int launch(const tdc_gemm_desc* d, hipStream_t st) {
     a.am = {d->a_map.seg, d->a_map.stride, d->a_map.off, d->a_map.inner};
     a.cm = {d->c_map.seg, d->c_map.stride, d->c_map.off, d->c_map.inner};
     a.rm = {d->r_map.seg, d->r_map.stride, d->r_map.off, d->r_map.inner};
+    if (use_256(d->M, d->N, d->K)) {
+        a.tiles_m = (d->M + 255) / 256;
+        a.tiles_n = (d->N + 255) / 256;
+        static bool attr256 = false;
+        if (!attr256) {
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm256_kernel<T>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS));
+            attr256 = true;
+        }
+        hipLaunchKernelGGL(gemm256_kernel<T>, dim3(a.tiles_m * a.tiles_n), dim3(512), T2_LDS, st, a);
+        return (int)hipGetLastError();
+    }
     a.tiles_m = (d->M + BM - 1) / BM;
     a.tiles_n = (d->N + BN - 1) / BN;
     static bool attr_set = false;
@@ -203,7 +436,7 @@ extern "C" int tdc_gemm(const tdc_gemm_desc* d, void* stream) {
         return TDC_E_BADARG;
     }
     if ((d->lda % 8) || (d->ldw % 8) || (d->ldc % 4) || (d->res && (d->ldres % 4)) || d->lda < d->K || d->ldw < d->K) return TDC_E_BADARG;
-    if (d->act == TDC_ACT_SWIGLU && d->res) return TDC_E_BADARG;
+    if (d->act != TDC_ACT_NONE && d->res) return TDC_E_BADARG;  /* activation epilogues take no residual */
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == TDC_F16) return launch<f16>(d, st);
     if (d->dtype == TDC_BF16) return launch<bf16>(d, st);

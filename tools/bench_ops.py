@@ -30,7 +30,8 @@ def main():
     for (M, N, K) in [(46656, 3456, 1152), (46656, 1152, 1152), (46656, 4352, 1152), (46656, 1152, 4352),
                       (46720, 4608, 1536), (46720, 1536, 1536), (46720, 8192, 1536), (46720, 1536, 4096),
                       (36864, 2048, 1024), (9216, 3584, 1024), (9216, 3584, 3584), (8192, 8192, 8192),
-                      (68016, 9216, 3584), (4096, 4096, 4096)]:
+                      (68016, 9216, 3584), (4096, 4096, 4096), (46656, 4352, 128), (46656, 4352, 256),
+                      (373248, 3456, 1152), (373248, 1152, 1152), (373248, 4352, 1152), (373248, 1152, 4352)]:
         a = torch.randn(M, K, device="cuda", generator=g).to(dtype)
         w = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).to(dtype)
         out = torch.empty(M, N, device="cuda", dtype=dtype)
