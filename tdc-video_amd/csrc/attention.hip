@@ -38,7 +38,7 @@ template <class T> __device__ __forceinline__ typename VecOf<T>::v4 tr_read(cons
 }
 
 // DK: padded head dim for the QK^T contraction (32/64/96); NDV: number of 16-wide output column tiles; QT: q tiles/wave
-template <class T, int DK, int NDV, int QT>
+template <class T, int DK, int NDV, int QT, bool VEC>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     typedef typename VecOf<T>::v8 v8;
     typedef typename VecOf<T>::v4 v4;
@@ -62,16 +62,27 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     const T* V = (const T*)p.v + b * p.v_bs + h * d;
     T* O = (T*)p.o + b * p.o_bs + h * d;
 
-    auto load8 = [&](const T* row, int c0) -> v8 {  // 8 elements row[c0..c0+7], zero beyond d
+    // 8 elements row[c0..c0+7].  Loads are UNCONDITIONAL (address clamped into the row) so that the compiler can keep
+    // all of a tile's loads in flight; elements beyond the head dim are zeroed later with `zero_tail`, after the wait.
+    auto load8 = [&](const T* row, int c0) -> v8 {
         v8 r;
-        if (p.vec_ok) {
-            if (c0 < d) r = *(const v8*)(row + c0);
-            else
+        if (VEC) {
+            const int cc = c0 < d ? c0 : d - 8;
+            r = *(const v8*)(row + cc);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const int cc = c0 + e < d ? c0 + e : d - 1; r[e] = row[cc]; }
+        }
+        return r;
+    };
+    auto zero_tail = [&](v8 r, int c0) -> v8 {
+        if (VEC) {
+            if (c0 >= d)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) r[e] = (T)0.f;
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) r[e] = (c0 + e < d) ? row[c0 + e] : (T)0.f;
+            for (int e = 0; e < 8; ++e) if (c0 + e >= d) r[e] = (T)0.f;
         }
         return r;
     };
@@ -85,41 +96,48 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         const T* row = Q + (long long)qr * p.q_rs;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-            qf[t][ks] = load8(row, ks * 32 + g * 8);
+            qf[t][ks] = zero_tail(load8(row, ks * 32 + g * 8), ks * 32 + g * 8);
         }
     }
 
     // ---- staging: K tile = 64 x NCH chunks, V tile = 64 x VCH chunks, 256 threads
     constexpr int KLD = (KT * NCH + 255) / 256, VLD = (KT * VCH + 255) / 256;
     v8 kreg[KLD], vreg[VLD];
+    // loads are issued unconditionally (indices clamped) so no exec-masked branch - and no vmcnt(0) - sits between them;
+    // only the LDS writes of a partially used last round are guarded
+    constexpr bool K_EXACT = (KT * NCH) % 256 == 0, V_EXACT = (KT * VCH) % 256 == 0;
     auto issue_loads = [&](int kv0) {
 #pragma unroll
         for (int i = 0; i < KLD; ++i) {
             int idx = tid + i * 256;
-            int key = idx / NCH, c = idx - key * NCH;
+            if (!K_EXACT && idx > KT * NCH - 1) idx = KT * NCH - 1;
+            const int key = idx / NCH, c = idx - key * NCH;
             int kr = kv0 + key; if (kr > p.sk - 1) kr = p.sk - 1;
-            if (idx < KT * NCH) kreg[i] = load8(K + (long long)kr * p.k_rs, c * 8);
+            kreg[i] = load8(K + (long long)kr * p.k_rs, c * 8);
         }
 #pragma unroll
         for (int i = 0; i < VLD; ++i) {
             int idx = tid + i * 256;
-            int key = idx / VCH, c = idx - key * VCH;
+            if (!V_EXACT && idx > KT * VCH - 1) idx = KT * VCH - 1;
+            const int key = idx / VCH, c = idx - key * VCH;
             int kr = kv0 + key; if (kr > p.sk - 1) kr = p.sk - 1;
-            if (idx < KT * VCH) vreg[i] = load8(V + (long long)kr * p.v_rs, c * 8);
+            vreg[i] = load8(V + (long long)kr * p.v_rs, c * 8);
         }
     };
     auto write_lds = [&]() {
 #pragma unroll
         for (int i = 0; i < KLD; ++i) {
-            int idx = tid + i * 256;
-            int key = idx / NCH, c = idx - key * NCH;
-            if (idx < KT * NCH) *(v8*)(Ks + key * KROW + ((c ^ (key & (NCHP - 1))) << 3)) = kreg[i];
+            const int idx = tid + i * 256;
+            const int key = idx / NCH, c = idx - key * NCH;
+            const v8 val = zero_tail(kreg[i], c * 8);
+            if (K_EXACT || idx < KT * NCH) *(v8*)(Ks + key * KROW + ((c ^ (key & (NCHP - 1))) << 3)) = val;
         }
 #pragma unroll
         for (int i = 0; i < VLD; ++i) {
-            int idx = tid + i * 256;
-            int key = idx / VCH, c = idx - key * VCH;
-            if (idx < KT * VCH) *(v8*)(Vs + key * VROW + (c << 3)) = vreg[i];
+            const int idx = tid + i * 256;
+            const int key = idx / VCH, c = idx - key * VCH;
+            const v8 val = zero_tail(vreg[i], c * 8);
+            if (V_EXACT || idx < KT * VCH) *(v8*)(Vs + key * VROW + (c << 3)) = val;
         }
     };
 
@@ -159,23 +177,26 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
                 for (int t = 0; t < QT; ++t) s[t][kt] = mfma16(kf, qf[t][ks], s[t][kt]);
             }
         }
-        // ---- online softmax (base 2)
+        // ---- online softmax in base 2 on the RAW scores: p = exp2(s*c - m) with c = scale*log2(e) folded into one fma;
+        //      keys beyond sk only exist in the last tile (wave-uniform branch)
         v8 pf[QT][2];
+        const bool partial = kv0 + KT > p.sk;
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-            float mx = -INFINITY;
+            if (partial) {
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+                for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int key = kv0 + kt * 16 + g * 4 + r;
-                    float x = (key < p.sk) ? s[t][kt][r] * p.scale_log2 : -INFINITY;
-                    s[t][kt][r] = x;
-                    mx = fmaxf(mx, x);
-                }
+                    for (int r = 0; r < 4; ++r)
+                        if (kv0 + kt * 16 + g * 4 + r >= p.sk) s[t][kt][r] = -INFINITY;
+            }
+            float mx = fmaxf(fmaxf(s[t][0][0], s[t][0][1]), fmaxf(s[t][0][2], s[t][0][3]));
+#pragma unroll
+            for (int kt = 1; kt < 4; ++kt)
+                mx = fmaxf(mx, fmaxf(fmaxf(s[t][kt][0], s[t][kt][1]), fmaxf(s[t][kt][2], s[t][kt][3])));
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run[t], mx);
+            const float m_new = fmaxf(m_run[t], mx * p.scale_log2);
             const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
             m_run[t] = m_new;
             float rs = 0.f;
@@ -183,7 +204,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float e = __builtin_amdgcn_exp2f(s[t][kt][r] - m_new);
+                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][kt][r], p.scale_log2, -m_new));
                     rs += e;
                     pf[t][kt >> 1][(kt & 1) * 4 + r] = (T)e;
                 }
@@ -223,7 +244,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 #pragma unroll
         for (int dt = 0; dt < NDV; ++dt) {
             const int c = dt * 16 + g * 4;
-            if (p.vec_ok && c + 3 < d) {
+            if (VEC && c + 3 < d) {
                 v4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (T)(o_acc[t][dt][e] * inv);
@@ -237,14 +258,14 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     }
 }
 
-template <class T, int DK, int NDV>
+template <class T, int DK, int NDV, bool VEC>
 int launch_qt(const AttnArgs& a, int batch, hipStream_t st) {
     if (a.sq > 64) {
         dim3 grid((a.sq + 127) / 128, a.heads, batch);
-        hipLaunchKernelGGL((attn_kernel<T, DK, NDV, 2>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attn_kernel<T, DK, NDV, 2, VEC>), grid, dim3(256), 0, st, a);
     } else {
         dim3 grid((a.sq + 63) / 64, a.heads, batch);
-        hipLaunchKernelGGL((attn_kernel<T, DK, NDV, 1>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attn_kernel<T, DK, NDV, 1, VEC>), grid, dim3(256), 0, st, a);
     }
     return (int)hipGetLastError();
 }
@@ -252,10 +273,17 @@ int launch_qt(const AttnArgs& a, int batch, hipStream_t st) {
 template <class T>
 int launch(const AttnArgs& a, int batch, hipStream_t st) {
     const int d = a.d;
-    if (d <= 16) return launch_qt<T, 32, 1>(a, batch, st);
-    if (d <= 32) return launch_qt<T, 32, 2>(a, batch, st);
-    if (d <= 64) return launch_qt<T, 64, 4>(a, batch, st);
-    if (d <= 80) return launch_qt<T, 96, 5>(a, batch, st);
+    if (a.vec_ok) {   // head_dim % 8 == 0, 16-byte aligned rows
+        if (d <= 16) return launch_qt<T, 32, 1, true>(a, batch, st);
+        if (d <= 32) return launch_qt<T, 32, 2, true>(a, batch, st);
+        if (d <= 64) return launch_qt<T, 64, 4, true>(a, batch, st);
+        if (d <= 80) return launch_qt<T, 96, 5, true>(a, batch, st);
+    } else {          // odd head dims / unaligned views (reduced-size fixtures only): element-wise loads
+        if (d <= 16) return launch_qt<T, 32, 1, false>(a, batch, st);
+        if (d <= 32) return launch_qt<T, 32, 2, false>(a, batch, st);
+        if (d <= 64) return launch_qt<T, 64, 4, false>(a, batch, st);
+        if (d <= 80) return launch_qt<T, 96, 5, false>(a, batch, st);
+    }
     return TDC_E_BADARG;
 }
 
@@ -275,7 +303,7 @@ extern "C" int tdc_attention(const tdc_attn_desc* d, void* stream) {
     a.heads = d->heads; a.d = d->head_dim; a.sq = d->sq; a.sk = d->sk;
     a.scale_log2 = d->scale * 1.4426950408889634f;
     auto al = [](const void* p, int bytes) { return ((uintptr_t)p % bytes) == 0; };
-    a.vec_ok = (d->head_dim % 8 == 0) && (d->q_rs % 8 == 0) && (d->k_rs % 8 == 0) && (d->v_rs % 8 == 0) &&
+    a.vec_ok = (d->head_dim % 8 == 0) && (d->head_dim >= 8) && (d->q_rs % 8 == 0) && (d->k_rs % 8 == 0) && (d->v_rs % 8 == 0) &&
                (d->o_rs % 4 == 0) && (d->q_bs % 8 == 0) && (d->k_bs % 8 == 0) && (d->v_bs % 8 == 0) &&
                (d->o_bs % 4 == 0) && al(d->q, 16) && al(d->k, 16) && al(d->v, 16) && al(d->o, 8);
     hipStream_t st = (hipStream_t)stream;
