@@ -35,13 +35,34 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_tanh(float x) {
-    const float k = 0.7978845608028654f;  // sqrt(2/pi)
-    float u = k * (x + 0.044715f * x * x * x);
-    return 0.5f * x * (1.0f + tanhf(u));
+// Activations for GEMM epilogues.  They run once per output element inside an MFMA-bound kernel, so they are written
+// with the two quarter-rate instructions v_exp_f32 / v_rcp_f32 and a handful of FMAs instead of libm calls
+// (erff / tanhf cost 30-40 VALU instructions per element and dominated the fc1 epilogues).
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// erf(x) by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. below fp32 round-off of the surrounding math)
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = fast_rcp(__builtin_fmaf(0.3275911f, ax, 1.0f));
+    float poly = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    poly = __builtin_fmaf(poly, t, 1.421413741f);
+    poly = __builtin_fmaf(poly, t, -0.284496736f);
+    poly = __builtin_fmaf(poly, t, 0.254829592f);
+    poly *= t;
+    const float e = fast_exp2(-1.4426950408889634f * ax * ax);
+    const float r = __builtin_fmaf(-poly, e, 1.0f);
+    return copysignf(r, x);
 }
-__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+// nn.GELU() / ACT2FN["gelu"]: 0.5 x (1 + erf(x / sqrt(2)))
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
+// "gelu_pytorch_tanh": 0.5 x (1 + tanh(u)) == x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3)   (exact identity)
+__device__ __forceinline__ float gelu_tanh(float x) {
+    const float k2 = 2.0f * 0.7978845608028654f * 1.4426950408889634f;  // 2 sqrt(2/pi) log2(e)
+    const float u = x * __builtin_fmaf(0.044715f * x, x, 1.0f);
+    return x * fast_rcp(1.0f + fast_exp2(-k2 * u));
+}
+__device__ __forceinline__ float silu(float x) { return x * fast_rcp(1.0f + fast_exp2(-1.4426950408889634f * x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -30,6 +30,8 @@ struct GemmArgs {
     int out_f32, res_f32, act;
     RowMap am, cm, rm;
     int tiles_m, tiles_n;
+    int debug;   // TDC_GEMM_DEBUG=1: skip the epilogue (timing experiments only; results are garbage)
+    int desync;  // phases of start-time stagger (0 = off)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -208,6 +210,121 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     epilogue<T, 4, 4>(p, acc, m0 + wm * 64, n0 + wn_ * 64, fr, g);
 }
 
+// ---- LDS-staged epilogue of the 256^2 kernel --------------------------------------------------------------------------
+// Row-per-lane stores straight from the MFMA layout touch 16 cache lines with 8 B each per instruction and are
+// store-ISSUE bound (~7 B/clk/CU, cdna_hip_programming.md T21): the 128 KiB C tile cost ~9 us per workgroup, 25 % of a
+// K=1152 GEMM.  Instead every wave transposes its 128x64 sub-tile through its own 16 KiB of the (now idle) pipeline LDS
+// and stores whole rows: one instruction = 8 rows x 128 B (16-bit out) or 4 rows x 256 B (fp32 out), 16 B per lane.
+// Bias / activation run before staging (MFMA layout, one bias vector per column tile); the fp32 residual add runs
+// after it, on full 256-B row segments.  XOR swizzle of the 16-B chunk with the row keeps both sides (nearly) conflict-free.
+template <class T, int ACT, int RES>
+__device__ __forceinline__ void epi_staged16(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase, int nbase,
+                                             int lane) {
+    typedef typename VecOf<T>::v4 v4;
+    typedef typename VecOf<T>::v8 v8;
+    const int fr = lane & 15, g = lane >> 4;
+    f32x4 bias[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = nbase + j * 16 + g * 4;
+        bias[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (p.bias && n < p.N) bias[j] = *(const f32x4*)(p.bias + n);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = i * 16 + fr;
+        const int m = mbase + r;
+        long long rrow = 0;
+        if (RES == 2) rrow = p.rm(m < p.M ? m : p.M - 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 v = acc[i][j] + bias[j];
+            if (ACT == TDC_ACT_GELU_ERF) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            } else if (ACT == TDC_ACT_GELU_TANH) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+            }
+            if (RES == 2) {   // 16-bit residual: add before the single rounding to T
+                const int n = nbase + j * 16 + g * 4;
+                if (n < p.N) {
+                    v4 rr = *(const v4*)((const T*)p.res + rrow * p.ldres + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+                }
+            }
+            v4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (T)v[e];
+            const int chunk = (j * 2 + (g >> 1)) ^ (r & 7);
+            *(v4*)(region + r * 128 + chunk * 16 + (g & 1) * 8) = o;
+        }
+    }
+    // same wave, in-order LDS queue: the reads below observe the writes above
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int r = q * 8 + (lane >> 3), k = lane & 7;
+        const v8 val = *(const v8*)(region + r * 128 + ((k ^ (r & 7)) << 4));
+        const int m = mbase + r, n = nbase + k * 8;
+        if (m < p.M && n < p.N) *(v8*)((T*)p.C + p.cm(m) * p.ldc + n) = val;
+    }
+}
+
+template <class T, int RES>
+__device__ __forceinline__ void epi_staged32(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase, int nbase,
+                                             int lane) {
+    const int fr = lane & 15, g = lane >> 4;
+    f32x4 bias[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = nbase + j * 16 + g * 4;
+        bias[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (p.bias && n < p.N) bias[j] = *(const f32x4*)(p.bias + n);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {       // 64 rows x 64 fp32 = 16 KiB per pass
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int r = ii * 16 + fr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int chunk = (j * 4 + g) ^ (r & 15);
+                *(f32x4*)(region + r * 256 + chunk * 16) = acc[half * 4 + ii][j] + bias[j];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int r = q * 4 + (lane >> 4), k = lane & 15;
+            f32x4 val = *(const f32x4*)(region + r * 256 + ((k ^ (r & 15)) << 4));
+            const int m = mbase + half * 64 + r, n = nbase + k * 4;
+            if (m < p.M && n < p.N) {
+                if (RES == 1) val += *(const f32x4*)((const float*)p.res + p.rm(m) * p.ldres + n);
+                *(f32x4*)((float*)p.C + p.cm(m) * p.ldc + n) = val;
+            }
+        }
+    }
+}
+
+// returns false when this (act, res, out) combination / alignment has no staged variant
+template <class T>
+__device__ __forceinline__ bool epilogue_staged(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase,
+                                                int nbase, int lane) {
+    const int res = p.res ? (p.res_f32 ? 1 : 2) : 0;
+    if (p.out_f32) {
+        if (p.act != TDC_ACT_NONE || res == 2) return false;
+        if (res == 1) epi_staged32<T, 1>(p, acc, region, mbase, nbase, lane);
+        else epi_staged32<T, 0>(p, acc, region, mbase, nbase, lane);
+        return true;
+    }
+    if (p.act == TDC_ACT_SWIGLU || res == 1 || (p.N & 7) || (p.ldc & 7) || ((uintptr_t)p.C & 15)) return false;
+    if (p.act == TDC_ACT_GELU_ERF) epi_staged16<T, TDC_ACT_GELU_ERF, 0>(p, acc, region, mbase, nbase, lane);
+    else if (p.act == TDC_ACT_GELU_TANH) epi_staged16<T, TDC_ACT_GELU_TANH, 0>(p, acc, region, mbase, nbase, lane);
+    else if (res == 2) epi_staged16<T, 0, 2>(p, acc, region, mbase, nbase, lane);
+    else epi_staged16<T, 0, 0>(p, acc, region, mbase, nbase, lane);
+    return true;
+}
+
 // ======================================================================================================================
 // 256x256x64 tile, 8 waves (2 M x 4 N, 128x64 per wave), 128 KiB LDS, "8-phase" schedule (cdna_hip_programming.md
 // T3+T4): every K tile is 4 phases of 16 MFMAs (one 64x32 quadrant of the wave's tile x K=64); each phase stages ONE
@@ -224,6 +341,7 @@ constexpr int T2_HALF = 128 * 64 * 2;         // 16 KiB
 constexpr int T2_BUF = 4 * T2_HALF;           // A0 A1 W0 W1
 constexpr int T2_LDS = 2 * T2_BUF;            // 128 KiB
 
+#define T2_EPI_BARRIER() __builtin_amdgcn_s_barrier()
 template <class T>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     typedef typename VecOf<T>::v8 v8;
@@ -289,6 +407,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     v8 fa[4][2], fb0[2][2], fb1[2][2];
 
     const int nk = p.K / 64;
+    // De-synchronise the CUs: all tiles take the same time, so without this every CU reaches its store epilogue at the
+    // same moment, the write path backs up, waves cannot retire and the next workgroup cannot start.  First-round
+    // workgroups start with a phase-dependent delay (a fraction of one tile time); the offsets then persist.
+    if (p.desync > 1 && (int)blockIdx.x < 256) {
+        const int phase = ((int)blockIdx.x >> 3) % p.desync;
+        const int naps = phase * nk * 10 / p.desync;       // ~ nk * 1.3 us per tile; s_sleep(32) ~ 1 us
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(6);
+    }
 #define T2_BARRIER() __builtin_amdgcn_s_barrier()
     // end of a load segment: retire this wave's LDS reads BEFORE the barrier (so that a later stage by any wave, incl.
     // the other, staggered, wave group, can never overwrite bytes still being read), then pin the MFMA cluster below it
@@ -377,6 +503,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #undef T2_MMA
 
     // ---- epilogue: lane holds C[m = m0 + wm*128 + 16 i + fr][n = n0 + wn*64 + 16 j + 4g .. +3]
+    if (p.debug == 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
+    if (p.debug != 2) {
+        T2_EPI_BARRIER();   // every wave is past its last LDS read: the pipeline buffers become staging space
+        if (epilogue_staged<T>(p, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn_ * 64, lane)) return;
+    }
     epilogue<T, 8, 4>(p, acc, m0 + wm * 128, n0 + wn_ * 64, fr, g);
 }
 
@@ -400,6 +537,8 @@ int launch(const tdc_gemm_desc* d, hipStream_t st) {
     a.lda = d->lda; a.ldw = d->ldw; a.ldc = d->ldc; a.ldres = d->ldres;
     a.M = d->M; a.N = d->N; a.K = d->K;
     a.out_f32 = d->out_f32; a.res_f32 = d->res_f32; a.act = d->act;
+    { const char* e = getenv("TDC_GEMM_DEBUG"); a.debug = e ? atoi(e) : 0; }
+    { const char* e = getenv("TDC_GEMM_DESYNC"); a.desync = e ? atoi(e) : 0; }
     a.am = {d->a_map.seg, d->a_map.stride, d->a_map.off, d->a_map.inner};
     a.cm = {d->c_map.seg, d->c_map.stride, d->c_map.off, d->c_map.inner};
     a.rm = {d->r_map.seg, d->r_map.stride, d->r_map.off, d->r_map.inner};
