@@ -179,7 +179,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--px", type=int, default=384, help="SigLIP input size (DINO uses px-6: 378); 336 -> 336/336")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--tower-batch", type=int, default=64)
+    ap.add_argument("--tower-batch", type=int, default=128)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

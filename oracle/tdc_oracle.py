@@ -440,6 +440,41 @@ def compress_chunk(chunk, prompt_ids, W, K, heads, audio_chunk=None):
     return comp, chunk
 
 
+def audio_tokens(beats_windows, sample_indices, n_frames, dist=10):
+    """a20 host part (tdc/cambrian_arch.py:1552-1598): BEATs features of consecutive 10-s windows ([1, n_w, 768],
+    50 tokens per second) -> [n_frames, 50, 768].  A second whose frame was dropped by the frame cap (sample_indices
+    == 0) is average-pooled together with the preceding kept second; short slices are adaptively pooled to 50 tokens;
+    the tail is zero padded.  `sample_indices` is the 0/1 vector of a1 (all ones when no cap)."""
+    audio_embeds, seg = [], []
+    pool = lambda x: F.adaptive_avg_pool2d(x, (50, x.shape[-1]))
+    for w, emb in enumerate(beats_windows):
+        k = w * dist
+        window = sample_indices[k:k + dist]
+        sample_len = len(window)
+        for idx, ind in enumerate(window):
+            token = emb[:, idx * 50:(idx + 1) * 50, :]
+            if token.shape[1] == 0:
+                continue
+            if token.shape[1] != 50:
+                token = pool(token)
+            if ind == 1:
+                if seg:
+                    audio_embeds.append(pool(torch.cat(seg, dim=1)))
+                    seg = []
+                seg.append(token)
+                if idx + 1 < sample_len and sample_indices[k + idx + 1] == 1:
+                    audio_embeds.append(token)
+                    seg = []
+            elif ind == 0:
+                seg.append(token)
+    if seg:
+        audio_embeds.append(pool(torch.cat(seg, dim=1)))
+    a = torch.cat(audio_embeds).flatten(0, 1)
+    pad = n_frames * 50 - a.shape[0]
+    a = F.pad(a, (0, 0, 0, pad))
+    return a.reshape(-1, 50, a.shape[-1])
+
+
 def chunk_table(T, seg_indices):
     """Segments -> <=8-frame chunks (tdc/cambrian_arch.py:1541-1545, :1603-1608): list of (start, end)."""
     split_points = [0] + [int(s) + 1 for s in seg_indices] + [T]
@@ -477,7 +512,8 @@ def tdc_compress(frames, seg_indices, prompt_ids, W, K, heads, max_visual_len, a
 
 
 # ----------------------------------------------------------------------------------------------- top level
-def encode_video(W, cfg, px_siglip, px_dino, image_size, input_ids, prompt_ids, audio=None, frame_cap=224):
+def encode_video(W, cfg, px_siglip, px_dino, image_size, input_ids, prompt_ids, audio=None, frame_cap=224,
+                 beats_windows=None):
     """prepare_inputs_labels_for_multimodal (tdc/cambrian_arch.py:864-1844) for ONE video sample
     (batch 1, one <image> token), returning inputs_embeds [1,S,H] plus every intermediate.
     W: reference-named state dict with the leading 'model.' stripped; cfg: dict of config keys."""
@@ -517,6 +553,9 @@ def encode_video(W, cfg, px_siglip, px_dino, image_size, input_ids, prompt_ids, 
     emb = W["embed_tokens_fn"]
     text_len = len(pre) + len(post)
     max_visual_len = cfg["tokenizer_model_max_length"] - cfg.get("inference_max_length", 16) - text_len
+    if beats_windows is not None:
+        audio = audio_tokens(beats_windows, samp, T)                                                  # a20
+        r["audio_tokens"] = audio
     vis = tdc_compress(frames, seg, prompt_ids if cfg.get("text_input", True) else None, W,
                        cfg.get("context_token_num", 16), cfg["qformer_heads"], max_visual_len, audio)  # a11-a20
     r["visual_tokens"] = vis

@@ -415,9 +415,11 @@ class CambrianMetaForCausalLM(ABC):
                     prompt_ids = [int(x) for x in prompt]      # pre-tokenised BERT ids
             audio = None
             if audios is not None and audios[i] is not None:
-                audio = audios[i].get("audio_tokens") if isinstance(audios[i], dict) else audios[i]
-                if audio is not None:
-                    audio = audio.to(eng.dev)
+                # {"beats_windows": [BEATs features of the consecutive 10-s windows, [1, n, 768] each]} or
+                # {"audio_tokens": [T, 50, 768]} (already interleaved); the BEATs encoder itself is not part of the path
+                audio = audios[i]
+                if not isinstance(audio, dict):
+                    audio = {"audio_tokens": audio.to(eng.dev)}
             keep = {}
             if is_video:
                 vis = eng.encode_video(vid_s.to(eng.dev), vid_d.to(eng.dev), tuple(image_sizes[i]),

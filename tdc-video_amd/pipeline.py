@@ -236,6 +236,28 @@ class VideoEncoder:
                               y_map=tmap)
         return h16, S
 
+    def audio_tokens(self, beats_windows, sample_indices, T):
+        """a20 (tdc/cambrian_arch.py:1552-1598): BEATs window features [1, n_w, 768] -> audio tokens [T, 50, 768] 16-bit
+        (pooling of short / dropped seconds with tdc_adaptive_pool_tokens, zero padded tail)."""
+        dt, dev = self.dtype, self.dev
+        wins = []
+        for w in beats_windows:
+            w2 = w.reshape(-1, w.shape[-1]).to(dev)
+            buf = torch.zeros(w2.shape[0], pad64(w2.shape[1]), device=dev, dtype=dt)
+            buf[:, : w2.shape[1]] = w2.to(dt)
+            wins.append(buf)
+        Da = beats_windows[0].shape[-1]
+        plan = seg.audio_plan([w.shape[0] for w in wins], [int(v) for v in sample_indices])
+        out = torch.zeros(T, 50, Da, device=dev, dtype=dt)
+
+        def pooled50(x):
+            return x if x.shape[0] == 50 else ops.adaptive_pool_tokens(x.contiguous(), x.shape[0], 50, 1)
+        for i, (parts, direct) in enumerate(plan[:T]):
+            toks = [pooled50(wins[w][s:e]) for (w, s, e) in parts]
+            x = toks[0] if len(toks) == 1 else pooled50(torch.cat(toks, 0))
+            out[i] = x[:, :Da]
+        return out
+
     def with_audio(self, X, T, N, audio):
         """a20: frames become [visual N | audio_proj(audio) Na] rows (tdc/cambrian_arch.py:1611-1614)."""
         c, dt, dev = self.c, self.dtype, self.dev
@@ -348,6 +370,14 @@ def encode_video_with(e, px_siglip, px_dino, image_size, budget_text_len, n_text
     N = X.shape[0] // T
     max_visual_len = cfg["tokenizer_model_max_length"] - cfg.get("inference_max_length", 16) - n_text_tokens
     pid = prompt_ids if cfg.get("text_input", True) else None
+    if isinstance(audio, dict):                                                                     # a20
+        if audio.get("audio_tokens") is not None:
+            audio = audio["audio_tokens"]
+        else:
+            samp = [0] * T0
+            for i in idx:
+                samp[i] = 1
+            audio = e.audio_tokens(audio["beats_windows"], samp, T)
     vis = compress_with(e, X, T, N, seg_idx, pid, max_visual_len, audio, keep)                      # a11-a19
     if keep is not None:
         keep.update(frame_indices=idx, selected=sel2, seg_indices=seg_idx, siglip_feat=sig, dino_feat=dino,

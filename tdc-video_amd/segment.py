@@ -125,6 +125,36 @@ def emit_plan(T, N, K, seg_indices, max_visual_len):
     return dict(chunks=chunks, comp_frames=comp_frames, comp_chunk=comp_chunk, key_frames=key_frames, src=src)
 
 
+def audio_plan(window_sizes, sample_indices, dist=10):
+    """a20 host logic (tdc/cambrian_arch.py:1552-1589): BEATs windows of `window_sizes[w]` tokens (50 per second) ->
+    one entry per emitted audio frame.  entry = (parts, direct): parts = [(window, start, end), ...] token slices (a
+    slice shorter than 50 is pooled to 50 first), direct = True when the reference appends the token verbatim,
+    False when it average-pools the concatenation of the parts back to 50 tokens (kept second + dropped seconds)."""
+    entries, seg = [], []
+    for w, n_w in enumerate(window_sizes):
+        k = w * dist
+        window = sample_indices[k:k + dist]
+        sample_len = len(window)
+        for idx, ind in enumerate(window):
+            s, e = idx * 50, min((idx + 1) * 50, n_w)
+            if e - s <= 0:
+                continue
+            part = (w, s, e)
+            if ind == 1:
+                if seg:
+                    entries.append((seg, False))
+                    seg = []
+                seg.append(part)
+                if idx + 1 < sample_len and sample_indices[k + idx + 1] == 1:
+                    entries.append(([part], True))
+                    seg = []
+            elif ind == 0:
+                seg.append(part)
+    if seg:
+        entries.append((seg, False))
+    return entries
+
+
 def shard_ranges(T, world):
     """contiguous frame ranges per rank: rank r owns [lo, hi)."""
     base, rem = divmod(T, world)

@@ -173,8 +173,17 @@ def lm_state(lm):
     return out
 
 
+FakeBeats = synth.FakeBeats
+
+
+def make_audio(T, seed):
+    g = torch.Generator().manual_seed(99 + seed)
+    wav = (0.1 * torch.randn(1, 16000 * T, generator=g)).half().float()   # stored as fp16 in the fixture
+    return {"audio_wav": wav, "audio_wav_mask": torch.zeros_like(wav, dtype=torch.bool)}
+
+
 def run_pipeline(name, T, image_size, prompt, cfg_over=None, seed=0, px=126, video_indices=(None,),
-                 keep_intermediates=True):
+                 keep_intermediates=True, audio=False):
     cfg = make_config(**(cfg_over or {}))
     lm = build_lm(cfg, seed)
     basis, coef = synth.make_basis_and_coef(T, px, seed=1234 + seed)
@@ -211,11 +220,18 @@ def run_pipeline(name, T, image_size, prompt, cfg_over=None, seed=0, px=126, vid
         return r
 
     lm.adapt_segment = adapt_wrap
+    audios = [None]
+    if audio:
+        lm.model.audio_encoder = types.SimpleNamespace(beats_path="fake", beats=FakeBeats())
+        aud = make_audio(T, seed)
+        audios = [aud]
+        with torch.no_grad():
+            lm.model.audio_proj.weight.mul_(3.0)
     with torch.inference_mode():
         out = lm.prepare_inputs_labels_for_multimodal(
             ids, None, None, None, None, images, image_sizes=[image_size],
             video_indices=(list(video_indices) if video_indices is not None else None),
-            prompts=[prompt], audios=[None])
+            prompts=[prompt], audios=audios)
     for h in hooks:
         h.remove()
     inputs_embeds = out[4]
@@ -235,6 +251,8 @@ def run_pipeline(name, T, image_size, prompt, cfg_over=None, seed=0, px=126, vid
         out_sva=cap["sva_out"][0].reshape(len(seg_cap["selected"][0]), -1, cfg.vision_hidden_size).numpy(), out_mm_proj=cap["mm_proj"][0].numpy(),
         cfg_json=np.array(json.dumps({k: v for k, v in vars(cfg).items()})),
     )
+    if audio:
+        arrs["audio_wav"] = aud["audio_wav"].numpy().astype(np.float16)
     if "vision_proj" in cap:
         arrs["out_vision_proj_first"] = cap["vision_proj"][0].numpy()
         arrs["n_qformer_calls"] = np.array(len(cap["vision_proj"]))
@@ -387,6 +405,11 @@ if __name__ == "__main__":
                                         # cambrian_arch.py:919 as soon as the frame cap triggers; the cap path is
                                         # only reachable with video_indices=None (direct call)
                                         video_indices=None, keep_intermediates=False)
+    man["pipeline_T40_audio"] = run_pipeline("pipeline_T40_audio.npz", 40, (384, 384), "what can you hear ?", seed=3,
+                                             cfg_over=dict(audio_input=True), audio=True, keep_intermediates=False,
+                                             # video_indices=[None] (generate()) leaves sample_indices = None and the
+                                             # reference's audio loop raises TypeError at cambrian_arch.py:1562
+                                             video_indices=None)
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(man, f, indent=1)
     print(json.dumps(man, indent=1))

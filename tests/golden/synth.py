@@ -24,3 +24,26 @@ def video_from_basis(basis, coef):
     flat = basis.astype(np.float32).reshape(nb, -1)
     vid = coef.astype(np.float32) @ flat
     return vid.reshape((coef.shape[0],) + basis.shape[1:]).astype(np.float32)
+
+
+class FakeBeats:
+    """Stand-in for BEATs.extract_features (tdc/audio_models/beats/BEATs.py:131-178; needs torchaudio, absent in the
+    build container): deterministic [1, n, 768] features with n = floor(seconds * 49.6) - a full 10-s window gives 496
+    frames, so its last second has 46 tokens and takes the reference's adaptive_avg_pool2d branch
+    (tdc/cambrian_arch.py:1567-1568).  Used by make_golden.py (plugged into the reference) and by the tests."""
+
+    def extract_features(self, wav, padding_mask=None, feature_only=True):
+        import torch
+        n = int(wav.shape[1] / 16000.0 * 49.6)
+        seg = wav[0, : n * 320].reshape(n, 320)
+        base = seg.mean(1, keepdim=True) * 50.0 + seg.std(1, keepdim=True)
+        emb = torch.sin(base * torch.arange(1, 769).float()[None] * 0.37) + base
+        return emb[None], None
+
+
+def beats_windows(wav, dist=10, sr=16000):
+    """BEATs features of the consecutive 10-s windows of wav [1, n] (tdc/cambrian_arch.py:1552-1560)."""
+    out = []
+    for k in range(0, int(wav.shape[1] / sr), dist):
+        out.append(FakeBeats().extract_features(wav[:, sr * k: sr * (k + dist)])[0])
+    return out

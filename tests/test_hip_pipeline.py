@@ -285,3 +285,25 @@ def test_sharded_world1_nccl_equals_serial():
     finally:
         dist.destroy_process_group()
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_full_pipeline_audio_vs_golden(dtype):
+    """a20: BEATs window features -> pooled audio tokens -> audio_proj -> KV of N+50 tokens, static frames N+50+1."""
+    W, o = load_fixture("pipeline_T40_audio.npz")
+    cfg = pipeline_cfg(o)
+    enc = make_encoder(W, cfg, dtype)
+    vid = torch.from_numpy(synth.video_from_basis(o["video_basis"], o["video_coef"]))
+    wins = synth.beats_windows(torch.from_numpy(o["audio_wav"].astype(np.float32)))
+    ids = torch.from_numpy(o["input_ids"])[0]
+    size = tuple(int(v) for v in o["image_size"])
+    keep = {}
+    vis = enc.encode_video(vid.cuda(), (vid + 0.01).cuda(), size, budget_text_len=len(ids), n_text_tokens=len(ids) - 1,
+                           prompt_ids=[int(i) for i in o["prompt_ids"]], audio={"beats_windows": wins}, keep=keep)
+    assert keep["seg_indices"] == o["out_seg_indices"].tolist()
+    emb = embed_fn(o)
+    pos = int(torch.where(ids == -200)[0][0])
+    full = torch.cat([emb(ids[:pos]), vis.float().cpu(), emb(ids[pos + 1:])])
+    ref = torch.from_numpy(o["out_inputs_embeds"])[0]
+    assert full.shape == ref.shape
+    assert rel(full, ref) < stage_tol(dtype)

@@ -86,6 +86,21 @@ def test_emit_plan_layout_and_clipping():
         assert seg.emit_plan(T, N, K, segi, budget)["src"] == want
 
 
+def test_audio_plan_matches_oracle():
+    g = torch.Generator().manual_seed(0)
+    wins = [torch.randn(1, 496, 8, generator=g), torch.randn(1, 496, 8, generator=g), torch.randn(1, 300, 8, generator=g)]
+    for samp in ([1] * 26, [1, 1, 0, 0, 1, 0, 1, 1, 1, 0] * 2 + [0, 1, 1, 0, 1, 1], [1] + [0] * 24 + [1]):
+        want = oracle.audio_tokens(wins, torch.tensor(samp), sum(samp))
+        plan = seg.audio_plan([496, 496, 300], samp)
+        pool = lambda x: x if x.shape[0] == 50 else torch.nn.functional.adaptive_avg_pool2d(x[None], (50, 8))[0]
+        got = []
+        for parts, direct in plan:
+            toks = [pool(wins[w][0, s:e]) for (w, s, e) in parts]
+            got.append(toks[0] if len(toks) == 1 else pool(torch.cat(toks, 0)))
+        assert len(got) == sum(samp)
+        assert torch.allclose(torch.stack(got), want, atol=1e-6)
+
+
 def test_shard_ranges():
     for T in (512, 100, 7):
         for w in (1, 2, 4, 8):

@@ -117,3 +117,33 @@ def test_pipeline_token_accounting():
     N = 4 * 5  # 4x4 tokens + newline column
     assert r["visual_tokens"].shape[0] == n_static * (N + 1) + n_comp * (4 + 1)
     assert int(o["n_qformer_calls"]) == sum(1 for s, e in chunks if e - s > 1)
+
+
+def test_full_pipeline_audio():
+    """a20: audio tokens interleaved into the Q-Former KV (N+50) and into the static frames (fake BEATs features)."""
+    W, o = load_fixture("pipeline_T40_audio.npz")
+    cfg = pipeline_cfg(o)
+    assert cfg["audio_input"]
+    W["embed_tokens_fn"] = embed_fn(o)
+    vid = torch.from_numpy(synth.video_from_basis(o["video_basis"], o["video_coef"]))
+    wins = synth.beats_windows(torch.from_numpy(o["audio_wav"].astype(np.float32)))
+    assert [w.shape[1] for w in wins] == [496] * 4
+    r = oracle.encode_video(W, cfg, vid, vid + 0.01, tuple(int(v) for v in o["image_size"]),
+                            torch.from_numpy(o["input_ids"]), torch.from_numpy(o["prompt_ids"]), beats_windows=wins)
+    assert np.array_equal(r["seg_indices"].numpy(), o["out_seg_indices"])
+    close(r["inputs_embeds"], o["out_inputs_embeds"])
+    # static frames carry N + 50 + 1 tokens, compressed ones K + 1
+    chunks = oracle.chunk_table(40, r["seg_indices"])
+    assert r["visual_tokens"].shape[0] == len(chunks) * (20 + 50 + 1) + (40 - len(chunks)) * 5
+
+
+def test_audio_tokens_with_dropped_frames():
+    """seconds dropped by the frame cap are pooled into the preceding kept second (cambrian_arch.py:1570-1589)."""
+    g = torch.Generator().manual_seed(0)
+    wins = [torch.randn(1, 496, 8, generator=g), torch.randn(1, 300, 8, generator=g)]   # 10 s + 6 s
+    samp = torch.tensor([1, 1, 0, 0, 1, 0, 1, 1, 1, 0, 0, 1, 1, 0, 1, 1])
+    out = oracle.audio_tokens(wins, samp, int(samp.sum()))
+    assert out.shape == (int(samp.sum()), 50, 8)
+    close(out[0], wins[0][0, :50])                                              # kept, next kept -> verbatim
+    close(out[1], torch.nn.functional.adaptive_avg_pool2d(wins[0][:, 50:200], (50, 8))[0])   # 1 kept + 2 dropped
+    close(out[2], torch.nn.functional.adaptive_avg_pool2d(wins[0][:, 200:300], (50, 8))[0])
