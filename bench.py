@@ -180,6 +180,7 @@ def main():
     ap.add_argument("--px", type=int, default=384, help="SigLIP input size (DINO uses px-6: 378); 336 -> 336/336")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tower-batch", type=int, default=128)
+    ap.add_argument("--two-streams", type=int, default=0, help="run the two towers on two HIP streams")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -205,6 +206,7 @@ def main():
     sd = random_state_dict(H, K, dev, gen, siglip_px=px_s)
     enc = VideoEncoder(sd, cfg, dtype=dtype, device=dev, siglip_heads=16, dino_heads=24, qformer_heads=12,
                        tower_batch=args.tower_batch)
+    enc.two_streams = bool(args.two_streams)
     sd_cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sd_cpu = {k: v.cpu() for k, v in sd.items()}

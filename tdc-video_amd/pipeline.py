@@ -40,6 +40,7 @@ class VideoEncoder:
         self._tables = {}
         self.K = cfg.get("context_token_num", 16)
         self.H = cfg["hidden_size"]
+        self.two_streams = False
 
     # ------------------------------------------------------------------------------------------------ towers
     def _bil(self, n_in, n_out):
@@ -350,6 +351,15 @@ def encode_video_with(e, px_siglip, px_dino, image_size, budget_text_len, n_text
         sel = torch.tensor(idx, device=px_siglip.device)
         px_siglip, px_dino = px_siglip[sel], px_dino[sel]
     T = len(idx)
+    # The two towers are independent (a5's second frame cap is a no-op once a1 capped at <= frame_cap frames): with
+    # `two_streams` they are enqueued on two HIP streams so one tower's kernel tails / memory-bound phases are
+    # filled by the other tower's workgroups.
+    side = None
+    if getattr(e, "two_streams", False) and T <= frame_cap and px_siglip.is_cuda:
+        side = torch.cuda.Stream(device=px_siglip.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            sig_early = e.tower("siglip", px_siglip)
     dino = e.tower("dino", px_dino)                                                                 # a4
     mns = cfg.get("max_num_segments", 24)
     if T <= mns + 1:                                                                                # a5
@@ -364,7 +374,12 @@ def encode_video_with(e, px_siglip, px_dino, image_size, budget_text_len, n_text
             T = len(sel2)
         sims = e.sims_tensor(dino, T).tolist()
         seg_idx = seg.select_segments(sims, mns)
-    sig = e.tower("siglip", px_siglip)                                                              # a3
+    if side is not None:
+        torch.cuda.current_stream().wait_stream(side)
+        sig = sig_early
+        sig.record_stream(torch.cuda.current_stream())
+    else:
+        sig = e.tower("siglip", px_siglip)                                                          # a3
     sizes = [tuple(image_size)] * T
     X, final_size = e.connector(sig, dino, T, sizes, keep)                                          # a6-a10
     N = X.shape[0] // T
