@@ -7,7 +7,6 @@ namespace {
 
 // One wave (64 lanes) per row; a row of up to 64*MAXV columns is kept in registers (MAXV elements per lane,
 // strided by 64 so that consecutive lanes touch consecutive addresses).
-constexpr int MAXV = 64;  // supports up to 4096 columns
 
 struct LnArgs {
     const void* x; int ldx; int x_f32;
@@ -19,13 +18,16 @@ struct LnArgs {
     RowMap xm, ym;
 };
 
-template <class T, int NV>
+// NV4 = number of 4-column groups per lane: lane l owns columns 4*(l + 64*i) .. +3 (16-byte fp32 / 8-byte 16-bit
+// accesses, consecutive lanes on consecutive addresses).  Requires cols % 4 == 0 and 4-element aligned rows.
+template <class T, int NV4>
 __global__ __launch_bounds__(256) void ln_kernel(LnArgs p) {
+    typedef typename VecOf<T>::v4 v4;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.rows) return;
     const long long xrow = p.xm(row), yrow = p.ym(row);
-    float v[NV];
+    f32x4 v[NV4];
     const float* addrow = nullptr;
     if (p.add) {
         int t = row % p.add_period;
@@ -37,50 +39,66 @@ __global__ __launch_bounds__(256) void ln_kernel(LnArgs p) {
     }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        int c = lane + i * 64;
-        float a = 0.f;
+    for (int i = 0; i < NV4; ++i) {
+        const int c = (lane + i * 64) * 4;
+        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (c < p.cols) {
-            a = p.x_f32 ? ((const float*)p.x)[xrow * p.ldx + c] : (float)((const T*)p.x)[xrow * p.ldx + c];
-            if (addrow) a += addrow[c];
+            if (p.x_f32) {
+                a = *(const f32x4*)((const float*)p.x + xrow * p.ldx + c);
+            } else {
+                v4 h = *(const v4*)((const T*)p.x + xrow * p.ldx + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = (float)h[e];
+            }
+            if (addrow) a += *(const f32x4*)(addrow + c);
         }
         v[i] = a;
-        s += a;
+        s += (a[0] + a[1]) + (a[2] + a[3]);
     }
     s = wave_sum(s);
     const float mean = s / (float)p.cols;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        int c = lane + i * 64;
-        float d = (c < p.cols) ? v[i] - mean : 0.f;
-        q += d * d;
+    for (int i = 0; i < NV4; ++i) {
+        const int c = (lane + i * 64) * 4;
+        if (c < p.cols) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
     }
     q = wave_sum(q);
     const float rstd = rsqrtf(q / (float)p.cols + p.eps);
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        int c = lane + i * 64;
+    for (int i = 0; i < NV4; ++i) {
+        const int c = (lane + i * 64) * 4;
         if (c < p.pad_cols) {
-            float o = 0.f;
-            if (c < p.cols) o = (v[i] - mean) * rstd * p.gamma[c] + p.beta[c];
-            if (p.y16) ((T*)p.y16)[yrow * p.ldy16 + c] = (T)o;
-            if (p.y32) p.y32[yrow * p.ldy32 + c] = o;
+            f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (c < p.cols) {
+                const f32x4 gm = *(const f32x4*)(p.gamma + c), bt = *(const f32x4*)(p.beta + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * gm[e] + bt[e];
+            }
+            if (p.y16) {
+                v4 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = (T)o[e];
+                *(v4*)((T*)p.y16 + yrow * p.ldy16 + c) = h;
+            }
+            if (p.y32) *(f32x4*)(p.y32 + yrow * p.ldy32 + c) = o;
         }
     }
 }
 
 template <class T>
 int launch_ln(const LnArgs& a, hipStream_t st) {
-    const int nv = (a.pad_cols + 63) / 64;
+    const int nv = (a.pad_cols + 255) / 256;
     dim3 grid((a.rows + 3) / 4), block(256);
     if (nv <= 1) hipLaunchKernelGGL((ln_kernel<T, 1>), grid, block, 0, st, a);
-    else if (nv <= 2) hipLaunchKernelGGL((ln_kernel<T, 2>), grid, block, 0, st, a);
-    else if (nv <= 12) hipLaunchKernelGGL((ln_kernel<T, 12>), grid, block, 0, st, a);
+    else if (nv <= 3) hipLaunchKernelGGL((ln_kernel<T, 3>), grid, block, 0, st, a);
+    else if (nv <= 4) hipLaunchKernelGGL((ln_kernel<T, 4>), grid, block, 0, st, a);
+    else if (nv <= 5) hipLaunchKernelGGL((ln_kernel<T, 5>), grid, block, 0, st, a);
+    else if (nv <= 6) hipLaunchKernelGGL((ln_kernel<T, 6>), grid, block, 0, st, a);
     else if (nv <= 16) hipLaunchKernelGGL((ln_kernel<T, 16>), grid, block, 0, st, a);
-    else if (nv <= 18) hipLaunchKernelGGL((ln_kernel<T, 18>), grid, block, 0, st, a);
-    else if (nv <= 24) hipLaunchKernelGGL((ln_kernel<T, 24>), grid, block, 0, st, a);
-    else if (nv <= MAXV) hipLaunchKernelGGL((ln_kernel<T, MAXV>), grid, block, 0, st, a);
     else return TDC_E_BADARG;
     return (int)hipGetLastError();
 }
@@ -178,6 +196,13 @@ extern "C" int tdc_layernorm(const tdc_ln_desc* d, void* stream) {
     if ((d->y16 && d->ldy16 < ldmin) || (d->y32 && d->ldy32 < ldmin)) {
         // outputs narrower than the padded width: only write the real columns
         a.pad_cols = d->cols;
+    }
+    // vector accesses: 4-element groups
+    if ((d->cols & 3) || (d->ldx & 3) || (d->y16 && (d->ldy16 & 3)) || (d->y32 && (d->ldy32 & 3)) ||
+        (d->add && (d->ldadd & 3)) || ((uintptr_t)d->x & 15 & (d->x_f32 ? 15 : 7)) ||
+        ((uintptr_t)d->gamma & 15) || ((uintptr_t)d->beta & 15)) {
+        fprintf(stderr, "[tdc_hip] tdc_layernorm: cols/ld must be multiples of 4 and pointers 16-byte aligned\n");
+        return TDC_E_BADARG;
     }
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == TDC_F16) return launch_ln<f16>(a, st);
