@@ -293,14 +293,28 @@ __device__ __forceinline__ void epi_staged32(const GemmArgs& p, f32x4 (&acc)[8][
                 *(f32x4*)(region + r * 256 + chunk * 16) = acc[half * 4 + ii][j] + bias[j];
             }
         }
+        // read back 4 rows x 256 B per instruction; the residual loads of a batch are issued back to back from clamped
+        // (always valid) addresses so that no branch - and no vmcnt(0) - separates them
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int r = q * 4 + (lane >> 4), k = lane & 15;
-            f32x4 val = *(const f32x4*)(region + r * 256 + ((k ^ (r & 15)) << 4));
-            const int m = mbase + half * 64 + r, n = nbase + k * 4;
-            if (m < p.M && n < p.N) {
-                if (RES == 1) val += *(const f32x4*)((const float*)p.res + p.rm(m) * p.ldres + n);
-                *(f32x4*)((float*)p.C + p.cm(m) * p.ldc + n) = val;
+        for (int qb = 0; qb < 16; qb += 8) {
+            f32x4 rr[8];
+            if (RES == 1) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = (qb + q) * 4 + (lane >> 4), k = lane & 15;
+                    int m = mbase + half * 64 + r, n = nbase + k * 4;
+                    if (m > p.M - 1) m = p.M - 1;
+                    if (n > p.N - 4) n = p.N - 4;
+                    rr[q] = *(const f32x4*)((const float*)p.res + p.rm(m) * p.ldres + n);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = (qb + q) * 4 + (lane >> 4), k = lane & 15;
+                f32x4 val = *(const f32x4*)(region + r * 256 + ((k ^ (r & 15)) << 4));
+                const int m = mbase + half * 64 + r, n = nbase + k * 4;
+                if (RES == 1) val += rr[q];
+                if (m < p.M && n < p.N) *(f32x4*)((float*)p.C + p.cm(m) * p.ldc + n) = val;
             }
         }
     }
