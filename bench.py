@@ -179,6 +179,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tower-batch", type=int, default=128)
     ap.add_argument("--two-streams", type=int, default=0, help="run the two towers on two HIP streams")
+    ap.add_argument("--dump-gemm-shapes", default=None, help="write the GEMM launches of one step (for tools/gemm_pmc)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -251,11 +252,17 @@ def main():
     fps = T * args.steps / dt
 
     # ---- roofline of the dominant kernel (tdc_gemm MFMA kernel): one extra profiled pass, events on the launch stream
-    ops.PROFILE = {"gemm": [], "attn": []}
+    ops.PROFILE = {"gemm": [], "attn": [], "gemm_shapes": []}
     step()
     torch.cuda.synchronize()
     prof = ops.PROFILE
     ops.PROFILE = None
+    if args.dump_gemm_shapes and rank == 0:
+        import collections
+        cnt = collections.Counter(prof["gemm_shapes"])
+        with open(args.dump_gemm_shapes, "w") as fh:
+            for (M_, N_, K_, act_, res_, of_), c in sorted(cnt.items(), key=lambda kv: -kv[0][0] * kv[0][1] * kv[0][2] * kv[1]):
+                fh.write("%d %d %d %d %d %d %d\n" % (M_, N_, K_, act_, res_, of_, c))
     g_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof["gemm"])
     g_fl = sum(w for _, _, w in prof["gemm"])
     a_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof["attn"])

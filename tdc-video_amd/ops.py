@@ -115,6 +115,8 @@ def gemm(a, w, bias=None, act=L.ACT_NONE, res=None, out=None, out_f32=False, M=N
     if e0 is not None:
         rn, rk = getattr(w, "_real_nk", (N, K))
         _prof_end("gemm", e0, 2.0 * M * rn * rk)
+        if "gemm_shapes" in PROFILE:
+            PROFILE["gemm_shapes"].append((M, N, K, act, int(res is not None), int(out_f32)))
     return out
 
 

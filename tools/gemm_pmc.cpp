@@ -1,0 +1,49 @@
+// Standalone (torch-free) driver of tdc_gemm for rocprofv3 --pmc runs: rocprofv3's counter collection segfaults inside
+// a torch process on this image (torch bundles ROCm 7.0 HSA, the profiler is 7.2), so the HBM-traffic counters of the
+// dominant kernel are collected here on the exact GEMM shapes bench.py launches (tools/gemm_shapes_T512.txt, written by
+// `python bench.py --dump-gemm-shapes ...`).  Build: see tools/run_gemm_pmc.sh.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include <string.h>
+#include "../include/tdc_hip.h"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+static void fill_bf16(std::vector<unsigned short>& v, unsigned seed, float scale) {
+    unsigned s = seed * 2654435761u + 12345u;
+    for (size_t i = 0; i < v.size(); ++i) {
+        s = s * 1664525u + 1013904223u;
+        float f = ((int)(s >> 9) % 2001 - 1000) * 0.001f * scale;   // uniform [-scale, scale]
+        unsigned u; memcpy(&u, &f, 4);
+        v[i] = (unsigned short)((u + 0x7FFF + ((u >> 16) & 1)) >> 16);
+    }
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) { fprintf(stderr, "usage: gemm_pmc shapes.txt [reps]\n"); return 2; }
+    int reps = argc > 2 ? atoi(argv[2]) : 2;
+    FILE* f = fopen(argv[1], "r");
+    if (!f) { perror("shapes"); return 2; }
+    int M, N, K, act, res, outf32, count;
+    hipStream_t st; CK(hipStreamCreate(&st));
+    while (fscanf(f, "%d %d %d %d %d %d %d", &M, &N, &K, &act, &res, &outf32, &count) == 7) {
+        size_t nA = (size_t)M * K, nW = (size_t)N * K, nC = (size_t)M * N;
+        std::vector<unsigned short> hA(nA), hW(nW);
+        fill_bf16(hA, M + K, 1.0f); fill_bf16(hW, N + K, 0.05f);
+        void *A, *W, *C; float* bias;
+        CK(hipMalloc(&A, nA * 2)); CK(hipMalloc(&W, nW * 2)); CK(hipMalloc(&C, nC * (outf32 ? 4 : 2))); CK(hipMalloc((void**)&bias, N * 4));
+        CK(hipMemcpy(A, hA.data(), nA * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(W, hW.data(), nW * 2, hipMemcpyHostToDevice));
+        CK(hipMemset(bias, 0, N * 4)); CK(hipMemset(C, 0, nC * (outf32 ? 4 : 2)));
+        tdc_gemm_desc d = {};
+        d.A = A; d.lda = K; d.W = W; d.ldw = K; d.C = C; d.ldc = (act == TDC_ACT_SWIGLU) ? N / 2 : N; d.bias = bias;
+        d.M = M; d.N = N; d.K = K; d.dtype = TDC_BF16; d.out_f32 = outf32; d.act = act;
+        if (res) { d.res = C; d.ldres = N; d.res_f32 = outf32; }   // in-place residual stream update
+        for (int r = 0; r < reps; ++r) { int rc = tdc_gemm(&d, st); if (rc) { fprintf(stderr, "tdc_gemm rc=%d\n", rc); return 1; } }
+        CK(hipStreamSynchronize(st));
+        printf("ran M=%d N=%d K=%d act=%d res=%d outf32=%d x%d\n", M, N, K, act, res, outf32, reps);
+        CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(C)); CK(hipFree(bias));
+    }
+    return 0;
+}
