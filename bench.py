@@ -270,8 +270,16 @@ def main():
     # the north_star's cross-attention block = the stacked K/V projection GEMM (+ tiny QK^T/PV): report it separately
     kv = [(e0.elapsed_time(e1), w) for e0, e1, w in prof["gemm"] if abs(w - max(x[2] for x in prof["gemm"])) < 1]
     achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+    # HBM-side traffic per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction), collected on the
+    # same GEMM launch list by the torch-free driver tools/gemm_pmc.cpp (rocprofv3 --pmc segfaults inside a torch
+    # process on this image) and committed under profiles/; null when that summary is absent or another workload runs.
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_gemm_pmc_summary.json")
+    if os.path.exists(pmc) and (T, K, H, args.tower_batch) == (512, 144, 3584, 128):
+        traffic = round(json.load(open(pmc))["per_launch_hbm_bytes"])
     roofline = dict(bound="mfma", achieved=round(achieved, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(achieved / MFMA_PEAK_TFLOPS, 4), traffic=None, kernel="gemm_kernel (tdc_gemm)",
+                    frac=round(achieved / MFMA_PEAK_TFLOPS, 4), traffic=traffic,
+                    kernel="gemm256_kernel / gemm_kernel (tdc_gemm)",
                     launches=len(prof["gemm"]), avg_launch_us=round(g_ms * 1e3 / max(1, len(prof["gemm"])), 2),
                     gemm_ms_per_step=round(g_ms, 2), gemm_tflop_per_step=round(g_fl / 1e12, 2),
                     attention=dict(ms_per_step=round(a_ms, 2),
