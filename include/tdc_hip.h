@@ -134,6 +134,36 @@ typedef struct {
 } tdc_qembed_desc;
 int tdc_qformer_embed(const tdc_qembed_desc* d, void* stream);
 
+/* ---- composite: one ViT tower forward (a2-a4) --------------------------------------------------------------------
+ * Replaces SiglipVisionTower._forward / DinoVisionTower._forward (tdc/multimodal_encoder/siglip_encoder.py:71-78,
+ * dino_encoder.py:109-120) incl. the HF SiglipVisionModel / Dinov2Model they wrap: patch-embed GEMM (+pos, +cls),
+ * n_layers x {LN, qkv GEMM, attention, out GEMM (+residual), LN, fc1 GEMM (+GELU-tanh / SwiGLU), fc2 GEMM (+residual)},
+ * optional final LN, bilinear resample of the token grid (cls dropped).  Weights are the prepared (padded, fused,
+ * LayerScale-folded) tensors of tdc-video_amd/weights.py; all pointers are device pointers except `layers`
+ * (host array).  The residual stream is fp32.  Nothing is allocated: the caller passes a workspace of at least
+ * tdc_vit_workspace_bytes() bytes (256-byte aligned). */
+typedef struct { const void* w; const float* b; int n, k; } tdc_lin;      /* w [n, k] 16-bit (padded), b [n] or NULL */
+typedef struct {
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    tdc_lin qkv, out, fc1, fc2;
+} tdc_vit_layer;
+typedef struct {
+    int dtype, dim, heads, head_dim, n_layers, patch, has_cls;
+    int act;                         /* TDC_ACT_GELU_TANH (SigLIP), TDC_ACT_SWIGLU / TDC_ACT_GELU_ERF (DINOv2) */
+    float eps;
+    tdc_lin patch_lin;               /* [pad64(dim), pad64(3*patch*patch)] */
+    const float* pos; int ldpos;     /* [P (+1), pad64(dim)] fp32 position rows for this patch grid (row 0 = cls) */
+    const float* cls_row;            /* cls + pos[0], [pad64(dim)] (NULL when !has_cls) */
+    const float *lnf_g, *lnf_b;      /* final LayerNorm (NULL: take the raw residual stream, SigLIP hidden_states[-1]) */
+    const tdc_vit_layer* layers_host;
+} tdc_vit_model;
+size_t tdc_vit_workspace_bytes(const tdc_vit_model* m, int B, int H, int W);
+/* px [B,3,H,W] (fp32 when px_f32 else 16-bit) -> out [B*out_grid*out_grid, ldo] 16-bit; idx0/idx1/frac: bilinear tables
+ * [out_grid] for the (H/patch)-wide grid (device).  H == W required (the reference pads frames to squares). */
+int tdc_vit_fwd(const tdc_vit_model* m, const void* px, int px_f32, int B, int H, int W, int out_grid,
+                const int* idx0, const int* idx1, const float* frac, void* out, int ldo, void* workspace,
+                size_t workspace_bytes, void* stream);
+
 /* library / device info */
 const char* tdc_version(void);
 int tdc_device_info(int* cu_count, size_t* hbm_bytes);

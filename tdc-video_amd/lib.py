@@ -58,6 +58,23 @@ class QEmbedDesc(C.Structure):
                 ("F", C.c_int), ("K", C.c_int), ("cols", C.c_int), ("dtype", C.c_int)]
 
 
+class Lin(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("n", C.c_int), ("k", C.c_int)]
+
+
+class VitLayer(C.Structure):
+    _fields_ = [("ln1_g", C.c_void_p), ("ln1_b", C.c_void_p), ("ln2_g", C.c_void_p), ("ln2_b", C.c_void_p),
+                ("qkv", Lin), ("out", Lin), ("fc1", Lin), ("fc2", Lin)]
+
+
+class VitModel(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("dim", C.c_int), ("heads", C.c_int), ("head_dim", C.c_int),
+                ("n_layers", C.c_int), ("patch", C.c_int), ("has_cls", C.c_int), ("act", C.c_int),
+                ("eps", C.c_float), ("patch_lin", Lin), ("pos", C.c_void_p), ("ldpos", C.c_int),
+                ("cls_row", C.c_void_p), ("lnf_g", C.c_void_p), ("lnf_b", C.c_void_p),
+                ("layers_host", C.POINTER(VitLayer))]
+
+
 # name -> (restype, argtypes); every symbol include/tdc_hip.h declares
 SIGNATURES = {
     "tdc_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
@@ -78,6 +95,10 @@ SIGNATURES = {
     "tdc_l2_normalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "tdc_sva_attention": (C.c_int, [C.POINTER(SvaAttnDesc), C.c_void_p]),
     "tdc_qformer_embed": (C.c_int, [C.POINTER(QEmbedDesc), C.c_void_p]),
+    "tdc_vit_workspace_bytes": (C.c_size_t, [C.POINTER(VitModel), C.c_int, C.c_int, C.c_int]),
+    "tdc_vit_fwd": (C.c_int, [C.POINTER(VitModel), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
+                              C.c_void_p]),
     "tdc_version": (C.c_char_p, []),
     "tdc_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
 }

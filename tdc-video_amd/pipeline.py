@@ -41,6 +41,7 @@ class VideoEncoder:
         self.K = cfg.get("context_token_num", 16)
         self.H = cfg["hidden_size"]
         self.two_streams = False
+        self.native_towers = True     # towers through the C++ composite tdc_vit_fwd (per-kernel Python path when False)
 
     # ------------------------------------------------------------------------------------------------ towers
     def _bil(self, n_in, n_out):
@@ -58,7 +59,60 @@ class VideoEncoder:
             outs.append(self._tower_batch(t, px[s:s + self.tower_batch].contiguous(), out_grid))
         return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 
+    # ---- native composite (csrc/api.cpp: tdc_vit_fwd): the whole tower batch is one C call ------------------------------
+    def _vit_struct(self, t, gh, gw):
+        """ctypes mirror of tdc_vit_model for tower `t` on a gh x gw patch grid (cached; keeps the arrays alive)."""
+        import ctypes as C
+        cache = t.setdefault("_c_structs", {})
+        if (gh, gw) in cache:
+            return cache[(gh, gw)]
+        pos, cls_row = Wt.tower_pos(t, gh, gw, self.dev)
+
+        def lin(l):
+            return L.Lin(l.w.data_ptr(), l.b.data_ptr() if l.b is not None else None, l.w.shape[0], l.w.shape[1])
+        layers = (L.VitLayer * len(t.layers))()
+        for i, Lr in enumerate(t.layers):
+            layers[i] = L.VitLayer(Lr.ln1_g.data_ptr(), Lr.ln1_b.data_ptr(), Lr.ln2_g.data_ptr(), Lr.ln2_b.data_ptr(),
+                                   lin(Lr.qkv), lin(Lr.out), lin(Lr.fc1), lin(Lr.fc2))
+        m = L.VitModel()
+        m.dtype = ops._dtcode(self.dtype)
+        m.dim, m.heads, m.head_dim, m.n_layers, m.patch, m.has_cls = t.dim, t.heads, t.head_dim, len(t.layers), t.patch, \
+            t.has_cls
+        m.act = {"gelu_tanh": L.ACT_GELU_TANH, "gelu_erf": L.ACT_GELU_ERF, "swiglu": L.ACT_SWIGLU}[t.act]
+        m.eps = t.eps
+        m.patch_lin = lin(t.patch_lin)
+        m.pos, m.ldpos = pos.data_ptr(), pos.stride(0)
+        m.cls_row = cls_row.data_ptr() if cls_row is not None else None
+        fl = t.get("final_ln")
+        m.lnf_g, m.lnf_b = (fl[0].data_ptr(), fl[1].data_ptr()) if fl else (None, None)
+        m.layers_host = layers
+        cache[(gh, gw)] = (m, layers, pos, cls_row)
+        return cache[(gh, gw)]
+
+    def _tower_batch_native(self, t, px, out_grid):
+        import ctypes as C
+        B, _, H, W = px.shape
+        assert H == W and px.is_contiguous() and len(t.layers) > 0   # trailing pixels (384 = 27*14 + 6) are dropped: "valid" conv
+        g = H // t.patch
+        m = self._vit_struct(t, g, g)[0]
+        lib = L.load()
+        need = lib.tdc_vit_workspace_bytes(C.byref(m), B, H, W)
+        ws = getattr(self, "_vit_ws", None)
+        if ws is None or ws.numel() < need:
+            ws = self._vit_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        D = t.dim
+        out = torch.empty(B * out_grid * out_grid, pad64(D), device=self.dev, dtype=self.dtype)
+        i0, i1, fr = self._bil(g, out_grid)
+        f32 = int(px.dtype == torch.float32)
+        assert f32 or px.dtype == self.dtype
+        L.check(lib.tdc_vit_fwd(C.byref(m), ops._ptr(px), f32, B, H, W, out_grid, ops._ptr(i0), ops._ptr(i1),
+                                ops._ptr(fr), ops._ptr(out), out.stride(0), ops._ptr(ws), ws.numel(), ops._stream()),
+                "tdc_vit_fwd")
+        return out
+
     def _tower_batch(self, t, px, out_grid):
+        if getattr(self, "native_towers", True) and ops.PROFILE is None and len(t.layers) > 0:
+            return self._tower_batch_native(t, px, out_grid)
         dt, dev = self.dtype, self.dev
         B = px.shape[0]
         D, Dp = t.dim, pad64(t.dim)

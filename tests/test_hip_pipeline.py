@@ -307,3 +307,43 @@ def test_full_pipeline_audio_vs_golden(dtype):
     ref = torch.from_numpy(o["out_inputs_embeds"])[0]
     assert full.shape == ref.shape
     assert rel(full, ref) < stage_tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_native_tower_composite_equals_kernel_sequence(dtype):
+    """tdc_vit_fwd (C++ composite) launches the same kernels as the per-kernel Python sequence: bit-identical output."""
+    import tdc_video_amd  # noqa: F401
+    from tdc_video_amd import weights as Wt
+    from tdc_video_amd.pipeline import VideoEncoder
+    for name, prep in (("siglip_small.npz", "siglip"), ("dino_small.npz", "dino")):
+        W, o = load_fixture(name)
+        enc = VideoEncoder.__new__(VideoEncoder)
+        enc.dtype, enc.dev, enc.tower_batch = dtype, torch.device("cuda"), 2
+        enc._tables = {}
+        enc.out_grid = [8, 8]
+        enc.towers = {prep: (Wt.prep_siglip if prep == "siglip" else Wt.prep_dino)(W, 4, dtype, enc.dev)}
+        px = torch.from_numpy(o["pixels"]).cuda()
+        enc.native_towers = True
+        a = enc.tower(prep, px)
+        enc.native_towers = False
+        b = enc.tower(prep, px)
+        assert torch.equal(a, b), name
+
+
+def test_tower_drops_trailing_pixels_like_valid_conv():
+    """384 = 27*14 + 6: the stride-14 'valid' patch conv ignores the last 6 rows/cols (HF SiglipVisionEmbeddings)."""
+    import tdc_video_amd  # noqa: F401
+    from tdc_video_amd import weights as Wt
+    from tdc_video_amd.pipeline import VideoEncoder
+    W, o = load_fixture("siglip_small.npz")
+    enc = VideoEncoder.__new__(VideoEncoder)
+    enc.dtype, enc.dev, enc.tower_batch = torch.float16, torch.device("cuda"), 64
+    enc._tables = {}
+    enc.out_grid = [8, 8]
+    enc.towers = {"siglip": Wt.prep_siglip(W, 4, torch.float16, enc.dev)}
+    px = torch.from_numpy(o["pixels"]).cuda()                      # 126 = 9 * 14
+    big = torch.randn(px.shape[0], 3, 131, 131, device="cuda")
+    big[:, :, :126, :126] = px
+    for native in (True, False):
+        enc.native_towers = native
+        assert torch.equal(enc.tower("siglip", big), enc.tower("siglip", px))
