@@ -286,6 +286,45 @@ __device__ __forceinline__ void epi_staged16(const GemmArgs& p, f32x4 (&acc)[8][
     }
 }
 
+// SwiGLU: columns are interleaved (x1_j, x2_j); each lane produces 2 outputs per accumulator tile, the wave's 128x64
+// sub-tile becomes 128 rows x 32 outputs (64-byte rows, 8 KiB).  Staging turns 32 four-byte stores per lane (16 rows
+// x 16 B per instruction) into 8 sixteen-byte stores (16 rows x 64 B per instruction).
+template <class T>
+__device__ __forceinline__ void epi_staged_swiglu(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase,
+                                                  int nbase, int lane) {
+    typedef __attribute__((ext_vector_type(2))) T v2;
+    typedef typename VecOf<T>::v8 v8;
+    const int fr = lane & 15, g = lane >> 4;
+    f32x4 bias[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = nbase + j * 16 + g * 4;
+        bias[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (p.bias && n < p.N) bias[j] = *(const f32x4*)(p.bias + n);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = i * 16 + fr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 v = acc[i][j] + bias[j];
+            v2 o;
+            o[0] = (T)(silu(v[0]) * v[1]);
+            o[1] = (T)(silu(v[2]) * v[3]);
+            // output column within the wave's 32: j*8 + 2g -> 16-B chunk j (4 per row), swizzled with the row
+            const int chunk = j ^ ((r >> 2) & 3);
+            *(v2*)(region + r * 64 + chunk * 16 + g * 4) = o;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int r = q * 16 + (lane >> 2), k = lane & 3;
+        const v8 val = *(const v8*)(region + r * 64 + ((k ^ ((r >> 2) & 3)) << 4));
+        const int m = mbase + r, nc = (nbase >> 1) + k * 8;
+        if (m < p.M && 2 * nc < p.N) *(v8*)((T*)p.C + p.cm(m) * p.ldc + nc) = val;
+    }
+}
+
 template <class T, int RES>
 __device__ __forceinline__ void epi_staged32(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase, int nbase,
                                              int lane) {
@@ -346,7 +385,13 @@ __device__ __forceinline__ bool epilogue_staged(const GemmArgs& p, f32x4 (&acc)[
         else epi_staged32<T, 0>(p, acc, region, mbase, nbase, lane);
         return true;
     }
-    if (p.act == TDC_ACT_SWIGLU || res == 1 || (p.N & 7) || (p.ldc & 7) || ((uintptr_t)p.C & 15)) return false;
+    if (res == 1 || (p.ldc & 7) || ((uintptr_t)p.C & 15)) return false;
+    if (p.act == TDC_ACT_SWIGLU) {
+        if (p.N & 15) return false;
+        epi_staged_swiglu<T>(p, acc, region, mbase, nbase, lane);
+        return true;
+    }
+    if (p.N & 7) return false;
     if (p.act == TDC_ACT_GELU_ERF) epi_staged16<T, TDC_ACT_GELU_ERF, 0>(p, acc, region, mbase, nbase, lane);
     else if (p.act == TDC_ACT_GELU_TANH) epi_staged16<T, TDC_ACT_GELU_TANH, 0>(p, acc, region, mbase, nbase, lane);
     else if (res == 2) epi_staged16<T, 0, 2>(p, acc, region, mbase, nbase, lane);
