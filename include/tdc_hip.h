@@ -164,6 +164,19 @@ int tdc_vit_fwd(const tdc_vit_model* m, const void* px, int px_f32, int B, int H
                 const int* idx0, const int* idx1, const float* frac, void* out, int ldo, void* workspace,
                 size_t workspace_bytes, void* stream);
 
+/* ---- frame pre-processing on the device -----------------------------------------------------------
+ * `process_images` for ONE tower (tdc/mm_datautils.py:270-314): frames uint8 [T, H, W, 3] (RGB, as decord / numpy give
+ * them) -> expand2square with the pad colour -> Pillow `Image.resize((R, R))` (bicubic with antialiasing, 8 bpc:
+ * byte-exact, same 22-bit fixed-point coefficients / pass order / uint8 intermediate as Resample.c) -> per-channel
+ * table lut[c*256 + v] = ((v / 255) - mean[c]) / std[c] (fp32, built by the host exactly as the HF image processor
+ * computes it) -> out [T, 3, R, R] 16-bit (or fp32).  bounds [R, 2] / coeffs [R, ksize] int32 are Resample.c's
+ * precompute_coeffs + normalize_coeffs_8bpc for max(H,W) -> R (tdc-video_amd/preprocess.py).  scratch:
+ * tdc_preprocess_scratch_bytes() bytes. */
+size_t tdc_preprocess_scratch_bytes(int T, int H, int W, int R);
+int tdc_preprocess_frames(const unsigned char* frames, int T, int H, int W, int R, const int* bounds, const int* coeffs,
+                          int ksize, int pad_r, int pad_g, int pad_b, const float* lut, void* out, int out_f32,
+                          int dtype, unsigned char* scratch, void* stream);
+
 /* library / device info */
 const char* tdc_version(void);
 int tdc_device_info(int* cu_count, size_t* hbm_bytes);

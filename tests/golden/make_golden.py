@@ -390,10 +390,48 @@ def make_towers():
     save("dino_small.npz", **a)
 
 
+def make_preprocess():
+    """tdc/mm_datautils.py process_images / expand2square, executed from the reference file itself (the module cannot be
+    imported here: iopath / decord are absent), with HF image processors built offline at reduced sizes."""
+    import ast
+    from PIL import Image
+    from transformers import BitImageProcessor, SiglipImageProcessor
+    src = open(ref_shims.REF_ROOT + "/tdc/mm_datautils.py").read()
+    tree = ast.parse(src)
+    fns = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("expand2square", "process_images")]
+    ns = {"Image": Image, "np": np, "torch": torch}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), "mm_datautils_extract", "exec"), ns)
+    proc_s = SiglipImageProcessor(size={"height": 42, "width": 42})
+    proc_d = BitImageProcessor(crop_size={"height": 56, "width": 56}, size={"shortest_edge": 56},
+                               image_mean=[0.485, 0.456, 0.406], image_std=[0.229, 0.224, 0.225])
+    rng = np.random.RandomState(7)
+    arrs = {}
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for tag, (H, W) in (("land", (45, 80)), ("port", (80, 45)), ("square", (50, 50))):
+            # smooth-ish frames (random low-res upsampled) + noise so that bicubic ringing / clipping is exercised
+            frames = rng.randint(0, 256, (3, H, W, 3)).astype(np.uint8)
+            frames[0, : H // 2] = 255
+            frames[1, :, : W // 3] = 0
+            out = ns["process_images"](list(frames), [proc_s, proc_d], None)
+            arrs["frames_" + tag] = frames
+            arrs["out_siglip_" + tag] = out[0].numpy()
+            arrs["out_dino_" + tag] = out[1].numpy()
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    arrs["siglip_mean"] = np.array(proc_s.image_mean, dtype=np.float64)
+    arrs["siglip_std"] = np.array(proc_s.image_std, dtype=np.float64)
+    arrs["dino_mean"] = np.array(proc_d.image_mean, dtype=np.float64)
+    arrs["dino_std"] = np.array(proc_d.image_std, dtype=np.float64)
+    save("preprocess_small.npz", **arrs)
+
+
 if __name__ == "__main__":
     import transformers
     man = dict(torch=torch.__version__, transformers=transformers.__version__, reference="Hoar012/TDC-Video @ 2025-08-29",
                bert=BERT_KW, H_LLM=H_LLM, C_VIS=C_VIS)
+    make_preprocess()
     make_qformer()
     make_sva()
     make_towers()
