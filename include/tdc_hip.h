@@ -164,6 +164,35 @@ int tdc_vit_fwd(const tdc_vit_model* m, const void* px, int px_f32, int B, int H
                 const int* idx0, const int* idx1, const float* frac, void* out, int ldo, void* workspace,
                 size_t workspace_bytes, void* stream);
 
+/* ---- composite: the batched Q-Former TDC compressor (a13-a18) -------------------------------------------------------
+ * Replaces `Qformer.bert(input_ids, query_embeds, encoder_hidden_states)` + `vision_proj` + `F.normalize`
+ * (tdc/cambrian_arch.py:1653-1667, tdc/Qformer.py:804-965) for ALL compressed frames of a video at once:
+ * enc [F*Nenc, ldenc] 16-bit (the frames' LLM-space tokens), query [nC*K, ldq] (query_proj of the pooled key frames),
+ * qsrc[f] = chunk of frame f, ids[Lt] = BERT prompt ids (Lt may be 0) -> out [F*K, ldo] 16-bit unit-norm context rows.
+ * Per layer: fused q|k|v GEMM, self-attention over S = K+Lt rows, dense+residual, LN; even layers: cross-attention of
+ * the K query rows against the frame's Nenc tokens (all layers' K/V projections come from ONE stacked GEMM,
+ * SURVEY D7); dual FFN (query rows / text rows).  Hidden stream fp32 + 16-bit copy. */
+typedef struct {
+    tdc_lin qkv, attn_out; const float *attn_ln_g, *attn_ln_b;
+    int has_cross, cross_idx;
+    tdc_lin cross_q, cross_out; const float *cross_ln_g, *cross_ln_b;
+    tdc_lin fq1, fq2; const float *fq_ln_g, *fq_ln_b;      /* intermediate_query / output_query */
+    tdc_lin ft1, ft2; const float *ft_ln_g, *ft_ln_b;      /* intermediate / output (text rows) */
+} tdc_qformer_layer;
+typedef struct {
+    int dtype, dim, heads, n_layers, H;
+    float eps;
+    const float *word, *pos; int ldw;
+    const float *emb_ln_g, *emb_ln_b;
+    tdc_lin cross_kv;                                       /* [n_cross*2*dim, pad64(H)]: (K_j | V_j) per cross layer */
+    tdc_lin vision_proj;                                    /* [pad64(H), pad64(dim)] */
+    const tdc_qformer_layer* layers_host;
+} tdc_qformer_model;
+size_t tdc_qformer_workspace_bytes(const tdc_qformer_model* m, int F, int K, int Lt, int Nenc);
+int tdc_qformer_fwd(const tdc_qformer_model* m, const void* enc, int ldenc, int F, int Nenc, const void* query, int ldq,
+                    const int* qsrc, const int* ids, int Lt, int K, void* out, int ldo, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
 /* ---- frame pre-processing on the device -----------------------------------------------------------
  * `process_images` for ONE tower (tdc/mm_datautils.py:270-314): frames uint8 [T, H, W, 3] (RGB, as decord / numpy give
  * them) -> expand2square with the pad colour -> Pillow `Image.resize((R, R))` (bicubic with antialiasing, 8 bpc:

@@ -55,7 +55,143 @@ int layernorm(const float* x, int ldx, void* y16, int ldy, const float* g, const
     return tdc_layernorm(&d, st);
 }
 
+struct QfWs {
+    size_t h32, h16, kv, qkv, ctx, ctxq, cq, t32, t32b, mq, mt, total;
+};
+
+QfWs qf_layout(const tdc_qformer_model* m, int F, int K, int Lt, int Nenc) {
+    const size_t S = (size_t)K + Lt, rows = (size_t)F * S, Dp = pad64i(m->dim);
+    const size_t ffn = m->layers_host[0].fq2.k;
+    QfWs w;
+    size_t off = 0;
+    w.h32 = off;  off += al256(rows * Dp * 4);
+    w.h16 = off;  off += al256(rows * Dp * 2);
+    w.kv = off;   off += al256((size_t)F * Nenc * m->cross_kv.n * 2);
+    w.qkv = off;  off += al256(rows * m->layers_host[0].qkv.n * 2);
+    w.ctx = off;  off += al256(rows * Dp * 2);
+    w.ctxq = off; off += al256((size_t)F * K * Dp * 2);
+    w.cq = off;   off += al256((size_t)F * K * Dp * 2);
+    w.t32 = off;  off += al256(rows * Dp * 4);
+    w.t32b = off; off += al256((size_t)F * (Lt > 0 ? Lt : 1) * Dp * 4);
+    w.mq = off;   off += al256((size_t)F * K * ffn * 2);
+    w.mt = off;   off += al256((size_t)F * (Lt > 0 ? Lt : 1) * ffn * 2);
+    w.total = off;
+    return w;
+}
+
+int ln_map(const float* x, int ldx, void* y16, float* y32, int ld, const float* g, const float* b, float eps, int rows,
+           int cols, int dtype, tdc_rowmap ymap, void* st) {
+    tdc_ln_desc d;
+    memset(&d, 0, sizeof(d));
+    d.x = x; d.ldx = ldx; d.x_f32 = 1; d.y16 = y16; d.ldy16 = ld; d.y32 = y32; d.ldy32 = ld; d.gamma = g; d.beta = b;
+    d.eps = eps; d.rows = rows; d.cols = cols; d.dtype = dtype; d.y_map = ymap;
+    return tdc_layernorm(&d, st);
+}
+
+int gemm_full(const void* A, int lda, const tdc_lin& L, void* C, int ldc, int M, int dtype, int act, int out_f32,
+              const void* res, int ldres, int res_f32, tdc_rowmap amap, tdc_rowmap cmap, tdc_rowmap rmap, void* st) {
+    tdc_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.A = A; d.lda = lda; d.W = L.w; d.ldw = L.k; d.C = C; d.ldc = ldc; d.bias = L.b; d.res = res; d.ldres = ldres;
+    d.M = M; d.N = L.n; d.K = L.k; d.dtype = dtype; d.out_f32 = out_f32; d.res_f32 = res_f32; d.act = act;
+    d.a_map = amap; d.c_map = cmap; d.r_map = rmap;
+    return tdc_gemm(&d, st);
+}
+
 }  // namespace
+
+extern "C" size_t tdc_qformer_workspace_bytes(const tdc_qformer_model* m, int F, int K, int Lt, int Nenc) {
+    if (!m || !m->layers_host || F <= 0 || K <= 0 || Nenc <= 0) return 0;
+    return qf_layout(m, F, K, Lt, Nenc).total;
+}
+
+extern "C" int tdc_qformer_fwd(const tdc_qformer_model* m, const void* enc, int ldenc, int F, int Nenc,
+                               const void* query, int ldq, const int* qsrc, const int* ids, int Lt, int K, void* out,
+                               int ldo, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!m || !enc || !query || !qsrc || !out || !workspace || F <= 0 || K <= 0 || Lt < 0) return TDC_E_BADARG;
+    const QfWs w = qf_layout(m, F, K, Lt, Nenc);
+    if (workspace_bytes < w.total || ((uintptr_t)workspace & 255)) return TDC_E_WORKSPACE;
+    char* ws = (char*)workspace;
+    const int D = m->dim, Dp = pad64i(D), dt = m->dtype, S = K + Lt, rows = F * S;
+    const int hd = D / m->heads;
+    float* h32 = (float*)(ws + w.h32);
+    void* h16 = ws + w.h16;
+    char* kv = ws + w.kv;
+    char* qkv = ws + w.qkv;
+    void* ctx = ws + w.ctx;
+    void* ctxq = ws + w.ctxq;
+    void* cq = ws + w.cq;
+    float* t32 = (float*)(ws + w.t32);
+    float* t32b = (float*)(ws + w.t32b);
+    void* mq = ws + w.mq;
+    void* mt = ws + w.mt;
+    const tdc_rowmap ident = {0, 0, 0, 0};
+    const tdc_rowmap qmap = {K, S, 0, 1};
+    const tdc_rowmap tmap = {Lt > 0 ? Lt : 1, S, K, 1};
+    hipStream_t st = (hipStream_t)stream;
+    // attention outputs only write the real columns: clear the K-padding columns once
+    if (Dp != D) {
+        if (hipMemsetAsync(ctx, 0, (size_t)rows * Dp * 2, st) != hipSuccess) return TDC_E_BADARG;
+        if (hipMemsetAsync(ctxq, 0, (size_t)F * K * Dp * 2, st) != hipSuccess) return TDC_E_BADARG;
+    }
+    {
+        tdc_qembed_desc e;
+        memset(&e, 0, sizeof(e));
+        e.query = query; e.ldq = ldq; e.qsrc = qsrc; e.word = m->word; e.pos = m->pos; e.ldw = m->ldw; e.ids = ids;
+        e.Lt = Lt; e.gamma = m->emb_ln_g; e.beta = m->emb_ln_b; e.eps = m->eps; e.h32 = h32; e.h16 = h16; e.ld = Dp;
+        e.F = F; e.K = K; e.cols = D; e.dtype = dt;
+        RET_IF(tdc_qformer_embed(&e, stream));
+    }
+    RET_IF(gemm_full(enc, ldenc, m->cross_kv, kv, m->cross_kv.n, F * Nenc, dt, TDC_ACT_NONE, 0, nullptr, 0, 0, ident,
+                     ident, ident, stream));
+    const float scale = 1.0f / sqrtf((float)hd);
+    for (int l = 0; l < m->n_layers; ++l) {
+        const tdc_qformer_layer& L = m->layers_host[l];
+        RET_IF(gemm_full(h16, Dp, L.qkv, qkv, L.qkv.n, rows, dt, TDC_ACT_NONE, 0, nullptr, 0, 0, ident, ident, ident,
+                         stream));
+        tdc_attn_desc a;
+        memset(&a, 0, sizeof(a));
+        a.q = qkv; a.k = qkv + (size_t)D * 2; a.v = qkv + (size_t)2 * D * 2; a.o = ctx;
+        a.q_bs = a.k_bs = a.v_bs = (long long)S * L.qkv.n; a.o_bs = (long long)S * Dp;
+        a.q_rs = a.k_rs = a.v_rs = L.qkv.n; a.o_rs = Dp;
+        a.batch = F; a.heads = m->heads; a.head_dim = hd; a.sq = S; a.sk = S; a.scale = scale; a.dtype = dt;
+        RET_IF(tdc_attention(&a, stream));
+        RET_IF(gemm_full(ctx, Dp, L.attn_out, t32, Dp, rows, dt, TDC_ACT_NONE, 1, h32, Dp, 1, ident, ident, ident,
+                         stream));
+        RET_IF(ln_map(t32, Dp, h16, h32, Dp, L.attn_ln_g, L.attn_ln_b, m->eps, rows, D, dt, ident, stream));
+        if (L.has_cross) {
+            RET_IF(gemm_full(h16, Dp, L.cross_q, cq, Dp, F * K, dt, TDC_ACT_NONE, 0, nullptr, 0, 0, qmap, ident, ident,
+                             stream));
+            tdc_attn_desc c;
+            memset(&c, 0, sizeof(c));
+            const size_t koff = (size_t)L.cross_idx * 2 * D * 2;
+            c.q = cq; c.k = kv + koff; c.v = kv + koff + (size_t)D * 2; c.o = ctxq;
+            c.q_bs = (long long)K * Dp; c.k_bs = c.v_bs = (long long)Nenc * m->cross_kv.n; c.o_bs = (long long)K * Dp;
+            c.q_rs = Dp; c.k_rs = c.v_rs = m->cross_kv.n; c.o_rs = Dp;
+            c.batch = F; c.heads = m->heads; c.head_dim = hd; c.sq = K; c.sk = Nenc; c.scale = scale; c.dtype = dt;
+            RET_IF(tdc_attention(&c, stream));
+            RET_IF(gemm_full(ctxq, Dp, L.cross_out, t32, Dp, F * K, dt, TDC_ACT_NONE, 1, h32, Dp, 1, ident, ident, qmap,
+                             stream));
+            RET_IF(ln_map(t32, Dp, h16, h32, Dp, L.cross_ln_g, L.cross_ln_b, m->eps, F * K, D, dt, qmap, stream));
+        }
+        RET_IF(gemm_full(h16, Dp, L.fq1, mq, L.fq2.k, F * K, dt, TDC_ACT_GELU_ERF, 0, nullptr, 0, 0, qmap, ident, ident,
+                         stream));
+        RET_IF(gemm_full(mq, L.fq2.k, L.fq2, t32, Dp, F * K, dt, TDC_ACT_NONE, 1, h32, Dp, 1, ident, ident, qmap,
+                         stream));
+        if (Lt > 0) {
+            RET_IF(gemm_full(h16, Dp, L.ft1, mt, L.ft2.k, F * Lt, dt, TDC_ACT_GELU_ERF, 0, nullptr, 0, 0, tmap, ident,
+                             ident, stream));
+            RET_IF(gemm_full(mt, L.ft2.k, L.ft2, t32b, Dp, F * Lt, dt, TDC_ACT_NONE, 1, h32, Dp, 1, ident, ident, tmap,
+                             stream));
+        }
+        RET_IF(ln_map(t32, Dp, h16, h32, Dp, L.fq_ln_g, L.fq_ln_b, m->eps, F * K, D, dt, qmap, stream));
+        if (Lt > 0)
+            RET_IF(ln_map(t32b, Dp, h16, h32, Dp, L.ft_ln_g, L.ft_ln_b, m->eps, F * Lt, D, dt, tmap, stream));
+    }
+    RET_IF(gemm_full(h16, Dp, m->vision_proj, out, ldo, F * K, dt, TDC_ACT_NONE, 0, nullptr, 0, 0, qmap, ident, ident,
+                     stream));
+    return tdc_l2_normalize(out, ldo, F * K, m->H, dt, stream);
+}
 
 extern "C" size_t tdc_vit_workspace_bytes(const tdc_vit_model* m, int B, int H, int W) {
     if (!m || B <= 0 || !m->layers_host) return 0;

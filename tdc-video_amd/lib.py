@@ -75,6 +75,21 @@ class VitModel(C.Structure):
                 ("layers_host", C.POINTER(VitLayer))]
 
 
+class QformerLayer(C.Structure):
+    _fields_ = [("qkv", Lin), ("attn_out", Lin), ("attn_ln_g", C.c_void_p), ("attn_ln_b", C.c_void_p),
+                ("has_cross", C.c_int), ("cross_idx", C.c_int),
+                ("cross_q", Lin), ("cross_out", Lin), ("cross_ln_g", C.c_void_p), ("cross_ln_b", C.c_void_p),
+                ("fq1", Lin), ("fq2", Lin), ("fq_ln_g", C.c_void_p), ("fq_ln_b", C.c_void_p),
+                ("ft1", Lin), ("ft2", Lin), ("ft_ln_g", C.c_void_p), ("ft_ln_b", C.c_void_p)]
+
+
+class QformerModel(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("dim", C.c_int), ("heads", C.c_int), ("n_layers", C.c_int), ("H", C.c_int),
+                ("eps", C.c_float), ("word", C.c_void_p), ("pos", C.c_void_p), ("ldw", C.c_int),
+                ("emb_ln_g", C.c_void_p), ("emb_ln_b", C.c_void_p), ("cross_kv", Lin), ("vision_proj", Lin),
+                ("layers_host", C.POINTER(QformerLayer))]
+
+
 # name -> (restype, argtypes); every symbol include/tdc_hip.h declares
 SIGNATURES = {
     "tdc_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
@@ -99,6 +114,10 @@ SIGNATURES = {
     "tdc_vit_fwd": (C.c_int, [C.POINTER(VitModel), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
                               C.c_void_p]),
+    "tdc_qformer_workspace_bytes": (C.c_size_t, [C.POINTER(QformerModel), C.c_int, C.c_int, C.c_int, C.c_int]),
+    "tdc_qformer_fwd": (C.c_int, [C.POINTER(QformerModel), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                  C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
+                                  C.c_void_p]),
     "tdc_preprocess_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "tdc_preprocess_frames": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,

@@ -41,6 +41,7 @@ class VideoEncoder:
         self.K = cfg.get("context_token_num", 16)
         self.H = cfg["hidden_size"]
         self.two_streams = False
+        self.native_qformer = True    # Q-Former through the C++ composite tdc_qformer_fwd
         self.native_towers = True     # towers through the C++ composite tdc_vit_fwd (per-kernel Python path when False)
 
     # ------------------------------------------------------------------------------------------------ towers
@@ -334,6 +335,63 @@ class VideoEncoder:
         pooled = ops.adaptive_pool_tokens(Xf, N, self.K, len(key_rows), keys, frame_rows=Nf)
         return ops.gemm(pooled, self.c.query_proj.w, self.c.query_proj.b)
 
+    def _qformer_struct(self):
+        """ctypes mirror of tdc_qformer_model (cached)."""
+        if getattr(self, "_qf_struct", None) is not None:
+            return self._qf_struct
+        c, qf = self.c, self.c.qformer
+
+        def lin(l):
+            return L.Lin(l.w.data_ptr(), l.b.data_ptr() if l.b is not None else None, l.w.shape[0], l.w.shape[1])
+        zero = L.Lin(None, None, 0, 0)
+        layers = (L.QformerLayer * len(qf.layers))()
+        for i, Lr in enumerate(qf.layers):
+            x = L.QformerLayer()
+            x.qkv, x.attn_out = lin(Lr.qkv), lin(Lr.attn_out)
+            x.attn_ln_g, x.attn_ln_b = Lr.attn_ln[0].data_ptr(), Lr.attn_ln[1].data_ptr()
+            if Lr.cross is not None:
+                x.has_cross, x.cross_idx = 1, Lr.cross.idx
+                x.cross_q, x.cross_out = lin(Lr.cross.q), lin(Lr.cross.out)
+                x.cross_ln_g, x.cross_ln_b = Lr.cross.ln[0].data_ptr(), Lr.cross.ln[1].data_ptr()
+            else:
+                x.has_cross, x.cross_idx, x.cross_q, x.cross_out = 0, 0, zero, zero
+            x.fq1, x.fq2 = lin(Lr.ffn_q.fc1), lin(Lr.ffn_q.fc2)
+            x.fq_ln_g, x.fq_ln_b = Lr.ffn_q.ln[0].data_ptr(), Lr.ffn_q.ln[1].data_ptr()
+            x.ft1, x.ft2 = lin(Lr.ffn_t.fc1), lin(Lr.ffn_t.fc2)
+            x.ft_ln_g, x.ft_ln_b = Lr.ffn_t.ln[0].data_ptr(), Lr.ffn_t.ln[1].data_ptr()
+            layers[i] = x
+        m = L.QformerModel()
+        m.dtype, m.dim, m.heads, m.n_layers, m.H, m.eps = ops._dtcode(self.dtype), qf.dim, self.qheads, len(qf.layers), \
+            c.H, 1e-12
+        m.word, m.pos, m.ldw = qf.word.data_ptr(), qf.pos.data_ptr(), qf.word.stride(0)
+        m.emb_ln_g, m.emb_ln_b = qf.emb_ln[0].data_ptr(), qf.emb_ln[1].data_ptr()
+        m.cross_kv, m.vision_proj = lin(qf.cross_kv), lin(c.vision_proj)
+        m.layers_host = layers
+        self._qf_struct = (m, layers)
+        return self._qf_struct
+
+    def _compress_native(self, enc, F, Nf, qtable, qs, prompt_ids):
+        import ctypes as C
+        m = self._qformer_struct()[0]
+        ids = None
+        if prompt_ids is not None and len(prompt_ids) > 0:
+            ids = torch.as_tensor(prompt_ids, dtype=torch.int32, device=self.dev).contiguous()
+            assert int(ids.max()) < self.c.qformer.word.shape[0] and len(ids) <= self.c.qformer.pos.shape[0]
+        Lt = 0 if ids is None else ids.numel()
+        K = self.K
+        assert qs.dtype == torch.int32 and qs.numel() >= F and (int(qs.max()) + 1) * K <= qtable.shape[0]
+        assert enc.shape[0] >= F * Nf and enc.shape[1] >= m.cross_kv.k and qtable.shape[1] >= pad64(m.dim)
+        lib = L.load()
+        need = lib.tdc_qformer_workspace_bytes(C.byref(m), F, K, Lt, Nf)
+        ws = getattr(self, "_qf_ws", None)
+        if ws is None or ws.numel() < need:
+            ws = self._qf_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        out = torch.empty(F * K, pad64(self.c.H), device=self.dev, dtype=self.dtype)
+        L.check(lib.tdc_qformer_fwd(C.byref(m), ops._ptr(enc), enc.stride(0), F, Nf, ops._ptr(qtable), qtable.stride(0),
+                                    ops._ptr(qs), ops._ptr(ids), Lt, K, ops._ptr(out), out.stride(0), ops._ptr(ws),
+                                    ws.numel(), ops._stream()), "tdc_qformer_fwd")
+        return out
+
     def compress_frames(self, Xf, Nf, frame_rows, qtable, qsrc, prompt_ids, keep=None):
         """a13-a18 for the frames `frame_rows` of Xf: Q-Former against queries qtable[qsrc[f]] -> [F*K, >=H] unit rows."""
         c, dev = self.c, self.dev
@@ -343,6 +401,11 @@ class VideoEncoder:
         enc_idx = torch.tensor([(0, f * Nf + i) for f in frame_rows for i in range(Nf)], dtype=torch.int32, device=dev)
         enc = ops.gather_rows([Xf], enc_idx, F * Nf, Hp)
         qs = torch.tensor(qsrc, dtype=torch.int32, device=dev)
+        if getattr(self, "native_qformer", True) and ops.PROFILE is None:
+            comp = self._compress_native(enc, F, Nf, qtable, qs, prompt_ids)
+            if keep is not None:
+                keep.update(compressed=comp)
+            return comp
         h16, S = self.qformer(enc, F, Nf, qtable, qs, prompt_ids)
         comp = ops.gemm(h16, c.vision_proj.w, c.vision_proj.b, M=F * K, a_map=(K, S, 0, 1))
         ops.l2_normalize(comp, F * K, H)

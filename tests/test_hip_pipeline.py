@@ -347,3 +347,24 @@ def test_tower_drops_trailing_pixels_like_valid_conv():
     for native in (True, False):
         enc.native_towers = native
         assert torch.equal(enc.tower("siglip", big), enc.tower("siglip", px))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name", ["pipeline_T40.npz", "pipeline_T40_audio.npz"])
+def test_native_qformer_composite_equals_kernel_sequence(name, dtype):
+    """tdc_qformer_fwd (C++ composite) == the per-kernel Python sequence, bit for bit (with and without audio KV)."""
+    W, o = load_fixture(name)
+    cfg = pipeline_cfg(o)
+    enc = make_encoder(W, cfg, dtype)
+    vid = torch.from_numpy(synth.video_from_basis(o["video_basis"], o["video_coef"])).cuda()
+    ids = torch.from_numpy(o["input_ids"])[0]
+    size = tuple(int(v) for v in o["image_size"])
+    audio = None
+    if "audio_wav" in o:
+        audio = {"beats_windows": synth.beats_windows(torch.from_numpy(o["audio_wav"].astype(np.float32)))}
+    outs = []
+    for native in (True, False):
+        enc.native_qformer = native
+        outs.append(enc.encode_video(vid, vid + 0.01, size, len(ids), len(ids) - 1, [int(i) for i in o["prompt_ids"]],
+                                     audio=audio))
+    assert torch.equal(outs[0], outs[1])
