@@ -13,7 +13,6 @@ kernel, timed live with events on the launch stream) and `cpu_baseline` (the ora
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time

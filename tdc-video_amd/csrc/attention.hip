@@ -261,9 +261,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 
 template <class T, int DK, int NDV, bool VEC>
 int launch_qt(const AttnArgs& a, int batch, hipStream_t st) {
-    static int force_qt = -1;
-    if (force_qt < 0) { const char* e = getenv("TDC_ATTN_QT"); force_qt = e ? atoi(e) : 0; }
-    if (a.sq > 64 && force_qt != 1) {
+    if (a.sq > 64) {
         dim3 grid((a.sq + 127) / 128, a.heads, batch);
         hipLaunchKernelGGL((attn_kernel<T, DK, NDV, 2, VEC>), grid, dim3(256), 0, st, a);
     } else {

@@ -30,8 +30,7 @@ struct GemmArgs {
     int out_f32, res_f32, act;
     RowMap am, cm, rm;
     int tiles_m, tiles_n;
-    int debug;   // TDC_GEMM_DEBUG=1: skip the epilogue (timing experiments only; results are garbage)
-    int desync;  // phases of start-time stagger (0 = off)
+    int debug;   // TDC_GEMM_DEBUG: 1 = skip the epilogue, 2 = direct (un-staged) epilogue - timing experiments only
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -482,14 +481,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     v8 fa[4][2], fb0[2][2], fb1[2][2];
 
     const int nk = p.K / 64;
-    // De-synchronise the CUs: all tiles take the same time, so without this every CU reaches its store epilogue at the
-    // same moment, the write path backs up, waves cannot retire and the next workgroup cannot start.  First-round
-    // workgroups start with a phase-dependent delay (a fraction of one tile time); the offsets then persist.
-    if (p.desync > 1 && (int)blockIdx.x < 256) {
-        const int phase = ((int)blockIdx.x >> 3) % p.desync;
-        const int naps = phase * nk * 10 / p.desync;       // ~ nk * 1.3 us per tile; s_sleep(32) ~ 1 us
-        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(6);
-    }
 #define T2_BARRIER() __builtin_amdgcn_s_barrier()
     // end of a load segment: retire this wave's LDS reads BEFORE the barrier (so that a later stage by any wave, incl.
     // the other, staggered, wave group, can never overwrite bytes still being read), then pin the MFMA cluster below it
@@ -613,7 +604,6 @@ int launch(const tdc_gemm_desc* d, hipStream_t st) {
     a.M = d->M; a.N = d->N; a.K = d->K;
     a.out_f32 = d->out_f32; a.res_f32 = d->res_f32; a.act = d->act;
     { const char* e = getenv("TDC_GEMM_DEBUG"); a.debug = e ? atoi(e) : 0; }
-    { const char* e = getenv("TDC_GEMM_DESYNC"); a.desync = e ? atoi(e) : 0; }
     a.am = {d->a_map.seg, d->a_map.stride, d->a_map.off, d->a_map.inner};
     a.cm = {d->c_map.seg, d->c_map.stride, d->c_map.off, d->c_map.inner};
     a.rm = {d->r_map.seg, d->r_map.stride, d->r_map.off, d->r_map.inner};

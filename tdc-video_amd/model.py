@@ -14,7 +14,6 @@ return values used only by in-LLM samplers (`connector_only=False`) are returned
 (what generate() passes) is treated as "not given" instead of raising TypeError when the frame cap triggers
 (tdc/cambrian_arch.py:919); training-only entry points raise NotImplementedError.
 """
-import math
 from abc import ABC, abstractmethod
 
 import torch

@@ -190,7 +190,6 @@ class VideoEncoder:
         ctx = ops.token_mean(aux[0], T, P)                                    # [T, Cp]
         q16 = torch.zeros(T * nq, Cp, device=dev, dtype=dt)
         q16[:, :C] = c.vision_query.to(dt).to(dev)[None, :]
-        M = T * nq
         for Lr in c.sva:
             cproj = ops.gemm(ctx, Lr.proj_context.w)                          # [T, Cp]
             cin = ops.gemm(cproj, Lr.proj_in_c.w, out_f32=True)               # [T, Cp] fp32: per-frame bias

@@ -2,7 +2,6 @@
 video frames - uint8 HWC frames in, one fp16/bf16 [T,3,R,R] tensor per tower out (SigLIP 384 / mean 0.5, DINOv2 378 /
 ImageNet mean).  The host only builds the small resampling tables (Pillow's Resample.c precompute_coeffs, done in
 double precision exactly like the C code) and the 3x256 normalisation table; the pixels never leave the GPU."""
-import ctypes as C
 import math
 
 import numpy as np
