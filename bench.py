@@ -185,11 +185,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    # test hooks (never set by the driver): TDC_BENCH_ONE_GPU=1 maps every rank onto GPU 0 and TDC_DIST_BACKEND=gloo
+    # swaps the transport, so the N>1 code path can be exercised on a 1-GPU box
+    if os.environ.get("TDC_BENCH_ONE_GPU"):
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("TDC_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     import tdc_video_amd  # noqa: F401
     from tdc_video_amd import ops
     from tdc_video_amd.pipeline import VideoEncoder
