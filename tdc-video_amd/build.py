@@ -10,6 +10,10 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libtdc_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+# attention reads its S / O accumulators with VALU every KV tile: keep MFMA results in VGPRs, otherwise the compiler
+# parks them in AGPRs and pays 160 v_accvgpr moves per tile (GEMM accumulators are only read in the epilogue, AGPRs fit)
+# -fno-honor-nans: fmaxf without the canonicalising v_max x,x (scores are finite; -inf only enters through the mask)
+FILE_FLAGS = {"attention.hip": ["-mllvm", "--amdgpu-mfma-vgpr-form", "-fno-honor-nans"]}
 
 
 def sources():
@@ -32,7 +36,7 @@ def build(force=False, verbose=True):
 
     def cc(src):
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
-        cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(src, []) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr))

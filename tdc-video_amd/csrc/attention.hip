@@ -17,6 +17,7 @@
 #include "../../include/tdc_hip.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -64,7 +65,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     T* O = (T*)p.o + b * p.o_bs + h * d;
 
     // 8 elements row[c0..c0+7].  Loads are UNCONDITIONAL (address clamped into the row) so that the compiler can keep
-    // all of a tile's loads in flight; elements beyond the head dim are zeroed later with `zero_tail`, after the wait.
+    // all of a tile's loads in flight.  Only Q's columns beyond the head dim are zeroed (`zero_tail`): K's clamped
+    // (finite, duplicated) tail then contributes 0 to the scores, V's tail only feeds output columns >= d that are
+    // never stored, and key rows beyond sk are clamped duplicates whose probabilities are exactly 0.
     auto load8 = [&](const T* row, int c0) -> v8 {
         v8 r;
         if (VEC) {
@@ -130,15 +133,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         for (int i = 0; i < KLD; ++i) {
             const int idx = tid + i * 256;
             const int key = idx / NCH, c = idx - key * NCH;
-            const v8 val = zero_tail(kreg[i], c * 8);
-            if (K_EXACT || idx < KT * NCH) *(v8*)(Ks + key * KROW + ((c ^ (key & (NCHP - 1))) << 3)) = val;
+            if (K_EXACT || idx < KT * NCH) *(v8*)(Ks + key * KROW + ((c ^ (key & (NCHP - 1))) << 3)) = kreg[i];
         }
 #pragma unroll
         for (int i = 0; i < VLD; ++i) {
             const int idx = tid + i * 256;
             const int key = idx / VCH, c = idx - key * VCH;
-            const v8 val = zero_tail(vreg[i], c * 8);
-            if (V_EXACT || idx < KT * VCH) *(v8*)(Vs + key * VROW + (c << 3)) = val;
+            if (V_EXACT || idx < KT * VCH) *(v8*)(Vs + key * VROW + (c << 3)) = vreg[i];
         }
     };
 
@@ -153,12 +154,15 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     }
 
     const int ntiles = (p.sk + KT - 1) / KT;
-    issue_loads(0);
-    for (int tile = 0; tile < ntiles; ++tile) {
+    const f32x4 c4 = {p.scale_log2, p.scale_log2, p.scale_log2, p.scale_log2};
+    // one KV tile; PARTIAL (keys beyond sk exist) is only instantiated for the last tile so the steady-state loop
+    // carries no mask compares
+    auto do_tile = [&](const int tile, auto partial_c) {
+        constexpr bool PARTIAL = decltype(partial_c)::value;
         __syncthreads();  // every wave finished reading the previous tile
         write_lds();
         __syncthreads();
-        if (tile + 1 < ntiles) issue_loads((tile + 1) * KT);
+        if (!PARTIAL) issue_loads((tile + 1) * KT);
         const int kv0 = tile * KT;
 
         // ---- S^T = K Q^T : s[t][kt] holds keys kv0 + 16 kt + 4 g + reg for query li
@@ -181,10 +185,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         // ---- online softmax in base 2 on the RAW scores: p = exp2(s*c - m) with c = scale*log2(e) folded into one fma;
         //      keys beyond sk only exist in the last tile (wave-uniform branch)
         v8 pf[QT][2];
-        const bool partial = kv0 + KT > p.sk;
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-            if (partial) {
+            if (PARTIAL) {
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -200,18 +203,26 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
             const float m_new = fmaxf(m_run[t], mx * p.scale_log2);
             const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
             m_run[t] = m_new;
-            float rs = 0.f;
+            const f32x4 nm4 = {-m_new, -m_new, -m_new, -m_new};
+            f32x4 rs4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < 4; ++kt) {
+                const f32x4 z = __builtin_elementwise_fma(s[t][kt], c4, nm4);   // v_pk_fma_f32
+                f32x4 e;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][kt][r], p.scale_log2, -m_new));
-                    rs += e;
-                    pf[t][kt >> 1][(kt & 1) * 4 + r] = (T)e;
+                    e[r] = __builtin_amdgcn_exp2f(z[r]);
+                    pf[t][kt >> 1][(kt & 1) * 4 + r] = (T)e[r];
                 }
+                rs4 += e;                                                       // v_pk_add_f32
+            }
+            const float rs = (rs4[0] + rs4[1]) + (rs4[2] + rs4[3]);
             l_run[t] = l_run[t] * alpha + rs;
+            // the running max only moves in the first few tiles: skip the O rescale when no lane's max changed
+            if (!__all(alpha == 1.0f)) {
 #pragma unroll
-            for (int dt = 0; dt < NDV; ++dt) o_acc[t][dt] *= alpha;
+                for (int dt = 0; dt < NDV; ++dt) o_acc[t][dt] *= alpha;
+            }
         }
         // ---- O^T += V^T P^T : A operand = V^T via transposed LDS reads
 #pragma unroll
@@ -230,7 +241,12 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
                 for (int t = 0; t < QT; ++t) o_acc[t][dt] = mfma16(vf, pf[t][sstep], o_acc[t][dt]);
             }
         }
-    }
+    };
+    issue_loads(0);
+    // tiles 0 .. ntiles-2 prefetch their successor; the last tile does not (it is run by the `true_type` instance,
+    // which also masks; a full last tile goes through it too with every key valid)
+    for (int tile = 0; tile < ntiles - 1; ++tile) do_tile(tile, std::false_type());
+    do_tile(ntiles - 1, std::true_type());
 
     // ---- finalise: lane holds O[q = q0 + 16 t + li][16 dt + 4 g + reg]
 #pragma unroll
