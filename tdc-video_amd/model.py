@@ -389,6 +389,7 @@ class CambrianMetaForCausalLM(ABC):
         is_video = type(images[0]) is list or images[0].ndim == 5
         bsz = input_ids.shape[0]
         visual = []          # per sample: [n_tokens, H] tensor on the engine device
+        spliced = []         # per sample: `visual[i]` already holds the text rows around the visual tokens
         final_size = []
         for i in range(bsz):
             if is_video:
@@ -421,9 +422,19 @@ class CambrianMetaForCausalLM(ABC):
                     audio = {"audio_tokens": audio.to(eng.dev)}
             keep = {}
             if is_video:
+                # a21 hand-off: when embed_tokens lives on the engine device in the engine dtype the
+                # emission gather also fetches the text embeddings and writes the inputs_embeds rows directly
+                splice = None
+                emb_w = getattr(getattr(model, "embed_tokens", None), "weight", None)
+                pos_img = torch.where(cur_ids == IMAGE_TOKEN_INDEX)[0].tolist()
+                if (getattr(self, "tdc_prefill_handoff", True) and emb_w is not None and emb_w.is_cuda
+                        and emb_w.device == eng.dev and emb_w.dtype == eng.dtype and len(pos_img) == 1):
+                    splice = {"table": emb_w, "before": cur_ids[:pos_img[0]].tolist(),
+                              "after": cur_ids[pos_img[0] + 1:].tolist()}
                 vis = eng.encode_video(vid_s.to(eng.dev), vid_d.to(eng.dev), tuple(image_sizes[i]),
                                        budget_text_len=self._budget_text_len(input_ids[i]), n_text_tokens=n_text,
-                                       prompt_ids=prompt_ids, audio=audio, keep=keep)
+                                       prompt_ids=prompt_ids, audio=audio, keep=keep, splice=splice)
+                spliced.append(splice is not None)
             else:
                 # single images: every image is a static frame, no segmentation / Q-Former (cambrian_arch.py:980-983)
                 sig = eng.tower("siglip", vid_s.to(eng.dev))
@@ -431,6 +442,8 @@ class CambrianMetaForCausalLM(ABC):
                 X, sizes = eng.connector(sig, dino, 1, [tuple(image_sizes[i])], keep)
                 vis = X[:, :H]
                 keep["final_size"] = sizes
+            if not is_video:
+                spliced.append(False)
             visual.append(vis)
             final_size.extend(keep["final_size"])
         # ---- a21: splice text embeddings and visual tokens, truncate, pad (cambrian_arch.py:1425-1495, :1712-1844)
@@ -458,6 +471,12 @@ class CambrianMetaForCausalLM(ABC):
             if len(img_pos) != 1:
                 raise NotImplementedError("one <image> token per sample (one video / image per prompt)")
             p = img_pos[0]
+            if spliced[i]:
+                n_vis = vis.shape[0] - (ids.shape[0] - 1)
+                new_embeds.append(vis)
+                new_labels.append(torch.cat([lab[:p], torch.full((n_vis,), IGNORE_INDEX, device=lab.device,
+                                                                 dtype=lab.dtype), lab[p + 1:]]))
+                continue
             text = embed(torch.cat([ids[:p], ids[p + 1:]]))
             vis = vis.to(text.dtype).to(text.device)
             new_embeds.append(torch.cat([text[:p], vis, text[p:]], 0))

@@ -415,29 +415,39 @@ class VideoEncoder:
     def query_width(self):
         return pad64(self.c.qformer.dim)
 
-    def emit(self, Xf, comp, pairs):
-        """a19: one gather over (frame tokens | context tokens | frame_seg) -> [len(pairs), H]."""
-        idx = torch.tensor(pairs, dtype=torch.int32, device=self.dev).contiguous()
+    def emit(self, Xf, comp, pairs, splice=None):
+        """a19: one gather over (frame tokens | context tokens | frame_seg) -> [len(pairs), H].
+        a21 hand-off (cambrian_arch.py:1712-1790 / cambrian_qwen.py:457-462): with
+        splice = {"table": embed_tokens.weight [V, H] 16-bit on this device, "before": ids, "after": ids} the same
+        launch also gathers the text embeddings, so the result is the LLM's inputs_embeds row block
+        [len(before) + len(pairs) + len(after), H] with no intermediate visual tensor."""
         tables = [Xf, comp if comp is not None else self.c.frame_seg, self.c.frame_seg]
+        if splice is not None:
+            tab = splice["table"]
+            assert tab.is_cuda and tab.device == Xf.device and tab.dtype == Xf.dtype and tab.shape[1] == self.c.H, \
+                "prefill hand-off needs embed_tokens on the engine device in the engine dtype"
+            pairs = [(3, int(t)) for t in splice["before"]] + list(pairs) + [(3, int(t)) for t in splice["after"]]
+            tables.append(tab)
+        idx = torch.tensor(pairs, dtype=torch.int32, device=self.dev).contiguous()
         return ops.gather_rows(tables, idx, len(pairs), self.c.H)
 
-    def compress(self, X, T, N, seg_indices, prompt_ids, max_visual_len, audio=None, keep=None):
+    def compress(self, X, T, N, seg_indices, prompt_ids, max_visual_len, audio=None, keep=None, splice=None):
         """X [T*N, Hp] -> emitted visual tokens [n, H] (tdc/cambrian_arch.py:1520-1709)."""
-        return compress_with(self, X, T, N, seg_indices, prompt_ids, max_visual_len, audio, keep)
+        return compress_with(self, X, T, N, seg_indices, prompt_ids, max_visual_len, audio, keep, splice)
 
     # ------------------------------------------------------------------------------------------------ top level
     def encode_video(self, px_siglip, px_dino, image_size, budget_text_len, n_text_tokens, prompt_ids, audio=None,
-                     frame_cap=224, keep=None):
+                     frame_cap=224, keep=None, splice=None):
         """One video: pixels -> emitted visual tokens [n, H] (S0-S10).  `budget_text_len` is the text length used by
         get_max_num_frames (cambrian_arch.py:753-759), `n_text_tokens` the non-image token count (:1499-1505)."""
         return encode_video_with(self, px_siglip, px_dino, image_size, budget_text_len, n_text_tokens, prompt_ids,
-                                 audio, frame_cap, keep)
+                                 audio, frame_cap, keep, splice)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
 # Orchestration over an "engine" (VideoEncoder on GPUs; the gloo tests of dist.py plug in a CPU test double that
 # implements tower / sims_tensor / connector / with_audio / make_queries / compress_frames / emit / query_width).
-def compress_with(e, X, T, N, seg_indices, prompt_ids, max_visual_len, audio=None, keep=None):
+def compress_with(e, X, T, N, seg_indices, prompt_ids, max_visual_len, audio=None, keep=None, splice=None):
     K = e.K
     Xf, Nf = e.with_audio(X, T, N, audio)
     plan = seg.emit_plan(T, Nf, K, seg_indices, max_visual_len)
@@ -455,11 +465,14 @@ def compress_with(e, X, T, N, seg_indices, prompt_ids, max_visual_len, audio=Non
             pairs.append((2, 0))
     if keep is not None:
         keep["plan"] = plan
+        keep["n_visual"] = len(pairs)
+    if splice is not None:
+        return e.emit(Xf, comp, pairs, splice)
     return e.emit(Xf, comp, pairs)
 
 
 def encode_video_with(e, px_siglip, px_dino, image_size, budget_text_len, n_text_tokens, prompt_ids, audio=None,
-                      frame_cap=224, keep=None):
+                      frame_cap=224, keep=None, splice=None):
     cfg = e.cfg
     T0 = px_siglip.shape[0]
     idx = seg.uniform_indices(T0, min(seg.get_max_num_frames(budget_text_len, cfg), frame_cap))     # a1
@@ -509,7 +522,7 @@ def encode_video_with(e, px_siglip, px_dino, image_size, budget_text_len, n_text
             for i in idx:
                 samp[i] = 1
             audio = e.audio_tokens(audio["beats_windows"], samp, T)
-    vis = compress_with(e, X, T, N, seg_idx, pid, max_visual_len, audio, keep)                      # a11-a19
+    vis = compress_with(e, X, T, N, seg_idx, pid, max_visual_len, audio, keep, splice)              # a11-a19 (+a21)
     if keep is not None:
         keep.update(frame_indices=idx, selected=sel2, seg_indices=seg_idx, siglip_feat=sig, dino_feat=dino,
                     final_size=final_size, X=X)

@@ -264,6 +264,41 @@ def test_mixin_boundary_vs_golden(name):
     assert torch.equal(out2[1][0], torch.arange(S))
 
 
+def test_prefill_handoff_equals_host_splice():
+    """with embed_tokens resident on the engine device the emission gather writes inputs_embeds directly
+    (text rows + visual rows in one launch); must equal the host-side cat of the reference flow bit for bit, and the
+    golden inputs_embeds within tolerance."""
+    from test_host_logic import build_stub_lm, tiny_config
+    W, o = load_fixture("pipeline_T40.npz")
+    lm = build_stub_lm(tiny_config())
+    m = lm.model
+    m.load_state_dict({k: v for k, v in W.items() if not k.startswith("vision_tower_aux_list")}, strict=False)
+    for i, t in enumerate(m.vision_tower_aux_list):
+        pre = "vision_tower_aux_list.%d.vision_tower." % i
+        t.load_model(state_dict={k[len(pre):]: v for k, v in W.items() if k.startswith(pre)})
+    with torch.no_grad():
+        m.embed_tokens.weight[[int(i) for i in o["used_embed_ids"]]] = torch.from_numpy(o["used_embed_rows"])
+    m.embed_tokens = m.embed_tokens.to("cuda", torch.float16)
+    eng = m.tdc_engine(dtype=torch.float16)
+    vid = torch.from_numpy(synth.video_from_basis(o["video_basis"], o["video_coef"]))
+    images = [vid.unsqueeze(0), (vid + 0.01).unsqueeze(0)]
+    ids = torch.from_numpy(o["input_ids"]).cuda()
+    size = tuple(int(v) for v in o["image_size"])
+    kw = dict(image_sizes=[size], video_indices=[None], prompts=[[int(i) for i in o["prompt_ids"]]], audios=[None])
+    calls = []
+    real_emit = eng.emit
+    eng.emit = lambda *a, **k: (calls.append(len(a) + len(k)), real_emit(*a, **k))[1]
+    lm.tdc_prefill_handoff = True
+    out_dev = lm.prepare_inputs_labels_for_multimodal(ids, None, torch.ones_like(ids), None, ids.clone(), images, **kw)
+    lm.tdc_prefill_handoff = False
+    out_host = lm.prepare_inputs_labels_for_multimodal(ids, None, torch.ones_like(ids), None, ids.clone(), images, **kw)
+    assert calls == [4, 3]                      # first call carried the splice argument
+    assert torch.equal(out_dev[4], out_host[4]) and torch.equal(out_dev[5], out_host[5])
+    assert torch.equal(out_dev[2], out_host[2])
+    ref = torch.from_numpy(o["out_inputs_embeds"])
+    assert out_dev[4].shape == ref.shape and rel(out_dev[4], ref) < stage_tol(torch.float16)
+
+
 def test_sharded_world1_nccl_equals_serial():
     """dist.ShardedVideoEncoder over RCCL with a single rank must equal the serial path bit for bit."""
     import os
