@@ -77,6 +77,11 @@ typedef struct {
     int q_rs, k_rs, v_rs, o_rs;
     int batch, heads, head_dim, sq, sk;
     float scale; int dtype;
+    /* optional additive score bias, fp32 (NULL = none): score(b,h,q,k) = scale*q.k + gate[(b*sq+q)*gate_rs + h] *
+     * bias[h*bias_hs + q*bias_rs + k].  BEATs gated relative position bias
+     * (tdc/audio_models/beats/backbone.py:650-661); needs sk % 4 == 0, head_dim <= 64. */
+    const float* bias; long long bias_hs; int bias_rs;
+    const float* gate; int gate_rs;
 } tdc_attn_desc;
 int tdc_attention(const tdc_attn_desc* d, void* stream);
 
@@ -205,6 +210,24 @@ size_t tdc_preprocess_scratch_bytes(int T, int H, int W, int R);
 int tdc_preprocess_frames(const unsigned char* frames, int T, int H, int W, int R, const int* bounds, const int* coeffs,
                           int ksize, int pad_r, int pad_g, int pad_b, const float* lut, void* out, int out_f32,
                           int dtype, unsigned char* scratch, void* stream);
+
+/* ---- BEATs audio front end --------------------------------------------------------------------------
+ * kaldi fbank as BEATs.preprocess calls it (tdc/audio_models/beats/BEATs.py:115-129: torchaudio.compliance.kaldi.fbank,
+ * 128 mel bins, 16 kHz, 25 ms / 10 ms, povey window, pre-emphasis 0.97, DC removal, dither 0, snip_edges) on B
+ * equal-length waveforms wav [B, n_samples] (fp16 or fp32, amplitude +-1; item stride wav_bs), followed by
+ * (x - mean) * inv_scale.  Host-built fp32 tables: window [400], twiddle [256][2] (cos, sin of 2 pi k / 512), banks
+ * [128][257], range [128][2] (non-zero span of each mel row).  Outputs (either may be NULL): plain fp32
+ * [B, frames, 128]; patches 16-bit [B * (frames/16) * 8, ldp] = the im2col of the 16x16 / stride-16 patch conv
+ * (BEATs.py:145-148), row (frame/16)*8 + mel/16, column (frame%16)*16 + mel%16.  tdc_fbank_frames(n) = frame count. */
+int tdc_fbank_frames(long long n_samples);
+int tdc_fbank(const void* wav, int wav_f32, long long n_samples, long long wav_bs, int B, const float* window,
+              const float* twiddle, const float* banks, const int* range, float* plain, void* patches, int ldp,
+              int dtype, float mean, float inv_scale, void* stream);
+/* gate of the gated relative position bias (backbone.py:652-657): q [rows, ldq] 16-bit (heads x head_dim columns, the
+ * un-scaled q_proj output); w2 [2, head_dim], b2 [2] = grep_linear rows / biases summed in groups of 4; grep_a
+ * [heads]; gate [rows, ldg] fp32 = ga * (gb * grep_a[h] - 1) + 2.  Consumed by tdc_attention's `gate`. */
+int tdc_relpos_gate(const void* q, int ldq, int rows, int heads, int head_dim, const float* w2, const float* b2,
+                    const float* grep_a, float* gate, int ldg, int dtype, void* stream);
 
 /* library / device info */
 const char* tdc_version(void);

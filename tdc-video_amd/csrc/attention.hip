@@ -28,6 +28,10 @@ struct AttnArgs {
     int heads, d, sq, sk;
     float scale_log2;
     int vec_ok;
+    // additive score bias (BEATs gated relative position bias): score(b,h,q,k) += gate[(b*sq+q)*gate_rs + h] *
+    // bias[h*bias_hs + q*bias_rs + k]; both fp32, bias rows 16-byte aligned (sk % 4 == 0)
+    const float* bias; long long bias_hs; int bias_rs;
+    const float* gate; int gate_rs;
 };
 
 constexpr int KT = 64;  // keys per tile
@@ -40,7 +44,7 @@ template <class T> __device__ __forceinline__ typename VecOf<T>::v4 tr_read(cons
 }
 
 // DK: padded head dim for the QK^T contraction (32/64/96); NDV: number of 16-wide output column tiles; QT: q tiles/wave
-template <class T, int DK, int NDV, int QT, bool VEC>
+template <class T, int DK, int NDV, int QT, bool VEC, bool BIAS>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     typedef typename VecOf<T>::v8 v8;
     typedef typename VecOf<T>::v4 v4;
@@ -143,6 +147,18 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         }
     };
 
+    // BIAS: lane (g, li) needs bias[h][q0 + 16 t + li][kv0 + 16 kt + 4 g .. +3] and the gate of that query row
+    const float* brow[QT];
+    float g2[QT];
+    if (BIAS) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            int qr = q0 + t * 16 + li;
+            if (qr > p.sq - 1) qr = p.sq - 1;
+            brow[t] = p.bias + h * p.bias_hs + (long long)qr * p.bias_rs + g * 4;
+            g2[t] = p.gate[((long long)b * p.sq + qr) * p.gate_rs + h] * 1.4426950408889634f;
+        }
+    }
     f32x4 o_acc[QT][NDV];
     float m_run[QT], l_run[QT];
 #pragma unroll
@@ -187,6 +203,18 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         v8 pf[QT][2];
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
+            if (BIAS) {
+                // scores move to the base-2 domain here: s = s*c + gate*log2(e)*bias (keys beyond sk: address clamped,
+                // value masked below)
+                const f32x4 gg = {g2[t], g2[t], g2[t], g2[t]};
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    int kc = kv0 + kt * 16;
+                    if (PARTIAL && kc + g * 4 > p.sk - 4) kc = p.sk - 4 - g * 4;
+                    const f32x4 bv = *(const f32x4*)(brow[t] + kc);
+                    s[t][kt] = __builtin_elementwise_fma(s[t][kt], c4, gg * bv);
+                }
+            }
             if (PARTIAL) {
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
@@ -200,14 +228,14 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
                 mx = fmaxf(mx, fmaxf(fmaxf(s[t][kt][0], s[t][kt][1]), fmaxf(s[t][kt][2], s[t][kt][3])));
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run[t], mx * p.scale_log2);
+            const float m_new = fmaxf(m_run[t], BIAS ? mx : mx * p.scale_log2);
             const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
             m_run[t] = m_new;
             const f32x4 nm4 = {-m_new, -m_new, -m_new, -m_new};
             f32x4 rs4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                const f32x4 z = __builtin_elementwise_fma(s[t][kt], c4, nm4);   // v_pk_fma_f32
+                const f32x4 z = BIAS ? s[t][kt] + nm4 : __builtin_elementwise_fma(s[t][kt], c4, nm4);   // v_pk_fma_f32
                 f32x4 e;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -275,14 +303,14 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     }
 }
 
-template <class T, int DK, int NDV, bool VEC>
+template <class T, int DK, int NDV, bool VEC, bool BIAS>
 int launch_qt(const AttnArgs& a, int batch, hipStream_t st) {
     if (a.sq > 64) {
         dim3 grid((a.sq + 127) / 128, a.heads, batch);
-        hipLaunchKernelGGL((attn_kernel<T, DK, NDV, 2, VEC>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attn_kernel<T, DK, NDV, 2, VEC, BIAS>), grid, dim3(256), 0, st, a);
     } else {
         dim3 grid((a.sq + 63) / 64, a.heads, batch);
-        hipLaunchKernelGGL((attn_kernel<T, DK, NDV, 1, VEC>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attn_kernel<T, DK, NDV, 1, VEC, BIAS>), grid, dim3(256), 0, st, a);
     }
     return (int)hipGetLastError();
 }
@@ -290,16 +318,23 @@ int launch_qt(const AttnArgs& a, int batch, hipStream_t st) {
 template <class T>
 int launch(const AttnArgs& a, int batch, hipStream_t st) {
     const int d = a.d;
+    if (a.bias) {     // biased scores: vector path only (BEATs: d = 64; reduced-size fixtures d = 16)
+        if (!a.vec_ok) return TDC_E_BADARG;
+        if (d <= 16) return launch_qt<T, 32, 1, true, true>(a, batch, st);
+        if (d <= 32) return launch_qt<T, 32, 2, true, true>(a, batch, st);
+        if (d <= 64) return launch_qt<T, 64, 4, true, true>(a, batch, st);
+        return TDC_E_BADARG;
+    }
     if (a.vec_ok) {   // head_dim % 8 == 0, 16-byte aligned rows
-        if (d <= 16) return launch_qt<T, 32, 1, true>(a, batch, st);
-        if (d <= 32) return launch_qt<T, 32, 2, true>(a, batch, st);
-        if (d <= 64) return launch_qt<T, 64, 4, true>(a, batch, st);
-        if (d <= 80) return launch_qt<T, 96, 5, true>(a, batch, st);
+        if (d <= 16) return launch_qt<T, 32, 1, true, false>(a, batch, st);
+        if (d <= 32) return launch_qt<T, 32, 2, true, false>(a, batch, st);
+        if (d <= 64) return launch_qt<T, 64, 4, true, false>(a, batch, st);
+        if (d <= 80) return launch_qt<T, 96, 5, true, false>(a, batch, st);
     } else {          // odd head dims / unaligned views (reduced-size fixtures only): element-wise loads
-        if (d <= 16) return launch_qt<T, 32, 1, false>(a, batch, st);
-        if (d <= 32) return launch_qt<T, 32, 2, false>(a, batch, st);
-        if (d <= 64) return launch_qt<T, 64, 4, false>(a, batch, st);
-        if (d <= 80) return launch_qt<T, 96, 5, false>(a, batch, st);
+        if (d <= 16) return launch_qt<T, 32, 1, false, false>(a, batch, st);
+        if (d <= 32) return launch_qt<T, 32, 2, false, false>(a, batch, st);
+        if (d <= 64) return launch_qt<T, 64, 4, false, false>(a, batch, st);
+        if (d <= 80) return launch_qt<T, 96, 5, false, false>(a, batch, st);
     }
     return TDC_E_BADARG;
 }
@@ -323,6 +358,14 @@ extern "C" int tdc_attention(const tdc_attn_desc* d, void* stream) {
     a.vec_ok = (d->head_dim % 8 == 0) && (d->head_dim >= 8) && (d->q_rs % 8 == 0) && (d->k_rs % 8 == 0) && (d->v_rs % 8 == 0) &&
                (d->o_rs % 4 == 0) && (d->q_bs % 8 == 0) && (d->k_bs % 8 == 0) && (d->v_bs % 8 == 0) &&
                (d->o_bs % 4 == 0) && al(d->q, 16) && al(d->k, 16) && al(d->v, 16) && al(d->o, 8);
+    a.bias = d->bias; a.bias_hs = d->bias_hs; a.bias_rs = d->bias_rs; a.gate = d->gate; a.gate_rs = d->gate_rs;
+    if (a.bias) {
+        if (!a.gate || d->sk % 4 != 0 || d->sk < 4 || d->bias_rs % 4 != 0 || d->bias_hs % 4 != 0 || !al(d->bias, 16) ||
+            d->gate_rs < d->heads) {
+            fprintf(stderr, "[tdc_hip] tdc_attention: bias needs a gate, sk %% 4 == 0 and 16-byte aligned fp32 rows\n");
+            return TDC_E_BADARG;
+        }
+    }
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == TDC_F16) return launch<f16>(a, d->batch, st);
     if (d->dtype == TDC_BF16) return launch<bf16>(a, d->batch, st);

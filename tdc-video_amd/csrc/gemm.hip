@@ -639,7 +639,8 @@ extern "C" int tdc_gemm(const tdc_gemm_desc* d, void* stream) {
         fprintf(stderr, "[tdc_hip] tdc_gemm: K %% 64 / N %% 4 violated (M=%d N=%d K=%d)\n", d->M, d->N, d->K);
         return TDC_E_BADARG;
     }
-    if ((d->lda % 8) || (d->ldw % 8) || (d->ldc % 4) || (d->res && (d->ldres % 4)) || d->lda < d->K || d->ldw < d->K) return TDC_E_BADARG;
+    if ((d->lda % 8) || (d->ldw % 8) || (d->ldc % 4) || (d->res && (d->ldres % 4)) || d->ldw < d->K) return TDC_E_BADARG;
+    /* lda < K is legal: rows of A may overlap (sliding-window views, e.g. the BEATs conv positional embedding) */
     if (d->act != TDC_ACT_NONE && d->res) return TDC_E_BADARG;  /* activation epilogues take no residual */
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == TDC_F16) return launch<f16>(d, st);

@@ -36,7 +36,9 @@ class AttnDesc(C.Structure):
                 ("q_bs", C.c_longlong), ("k_bs", C.c_longlong), ("v_bs", C.c_longlong), ("o_bs", C.c_longlong),
                 ("q_rs", C.c_int), ("k_rs", C.c_int), ("v_rs", C.c_int), ("o_rs", C.c_int),
                 ("batch", C.c_int), ("heads", C.c_int), ("head_dim", C.c_int), ("sq", C.c_int), ("sk", C.c_int),
-                ("scale", C.c_float), ("dtype", C.c_int)]
+                ("scale", C.c_float), ("dtype", C.c_int),
+                ("bias", C.c_void_p), ("bias_hs", C.c_longlong), ("bias_rs", C.c_int),
+                ("gate", C.c_void_p), ("gate_rs", C.c_int)]
 
 
 class GatherTables(C.Structure):
@@ -122,6 +124,11 @@ SIGNATURES = {
     "tdc_preprocess_frames": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                         C.c_void_p]),
+    "tdc_fbank_frames": (C.c_int, [C.c_longlong]),
+    "tdc_fbank": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    "tdc_relpos_gate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "tdc_version": (C.c_char_p, []),
     "tdc_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
 }

@@ -152,9 +152,10 @@ def layernorm(x, gamma, beta, eps, cols, dtype, y16=None, y32=None, add=None, ad
     return y16, y32
 
 
-def attention(q, k, v, out, batch, heads, head_dim, sq, sk, scale, q_bs, k_bs, v_bs, o_bs):
+def attention(q, k, v, out, batch, heads, head_dim, sq, sk, scale, q_bs, k_bs, v_bs, o_bs, bias=None, gate=None):
     """q/k/v/out: 2-D views [tokens, ld] whose element (b, s, h, c) sits at base + b*bs + s*stride(0) + h*head_dim + c.
-    Tensors may be column-offset views of a fused QKV buffer."""
+    Tensors may be column-offset views of a fused QKV buffer.  bias fp32 [heads, sq, sk] + gate fp32 [batch*sq, >=heads]
+    add gate[b*sq+q, h] * bias[h, q, k] to the scaled scores (BEATs gated relative position bias)."""
     for t in (q, k, v, out):
         assert t.is_cuda and t.dim() == 2 and t.stride(1) == 1
     assert q.dtype == k.dtype == v.dtype == out.dtype
@@ -171,6 +172,13 @@ def attention(q, k, v, out, batch, heads, head_dim, sq, sk, scale, q_bs, k_bs, v
     d.q_rs, d.k_rs, d.v_rs, d.o_rs = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
     d.batch, d.heads, d.head_dim, d.sq, d.sk = batch, heads, head_dim, sq, sk
     d.scale, d.dtype = scale, _dt(q)
+    if bias is not None:
+        assert gate is not None and bias.is_cuda and gate.is_cuda and bias.dtype == gate.dtype == torch.float32
+        assert bias.dim() == 3 and bias.is_contiguous() and tuple(bias.shape) == (heads, sq, sk) and sk % 4 == 0
+        assert gate.dim() == 2 and gate.stride(1) == 1 and gate.shape[0] >= batch * sq and gate.shape[1] >= heads
+        assert head_dim <= 64 and head_dim % 8 == 0
+        d.bias, d.bias_hs, d.bias_rs = bias.data_ptr(), sq * sk, sk
+        d.gate, d.gate_rs = gate.data_ptr(), gate.stride(0)
     e0 = _prof_begin("attn")
     L.check(L.load().tdc_attention(C.byref(d), _stream()), "tdc_attention")
     _prof_end("attn", e0, 4.0 * batch * heads * sq * sk * head_dim)
@@ -336,3 +344,35 @@ def qformer_embed(query, qsrc, word, pos, ids, gamma, beta, eps, F, K, cols, dty
     d.F, d.K, d.cols, d.dtype = F, K, cols, _dtcode(dtype)
     L.check(L.load().tdc_qformer_embed(C.byref(d), _stream()), "tdc_qformer_embed")
     return h32, h16
+
+
+def fbank(wav, tables, dtype, want_plain=False, mean=15.41663, std=6.55582):
+    """wav [B, n] fp16/fp32 on the GPU -> (patches [B*(m//16)*8, 256] `dtype`, plain fp32 [B, m, 128] or None, m).
+    tables = (window, twiddle, banks, range) device tensors (beats.fbank_tables)."""
+    assert wav.is_cuda and wav.dim() == 2 and wav.stride(1) == 1 and wav.dtype in (torch.float16, torch.float32)
+    B, n = wav.shape
+    m = L.load().tdc_fbank_frames(n)
+    assert m >= 16, "audio window shorter than one 16-frame patch row"
+    window, tw, banks, rng = tables
+    assert window.numel() == 400 and tw.numel() == 512 and tuple(banks.shape) == (128, 257) and tuple(rng.shape) == (128, 2)
+    for t in (window, tw, banks):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+    assert rng.is_cuda and rng.dtype == torch.int32 and rng.is_contiguous()
+    patches = torch.empty(B * (m // 16) * 8, 256, device=wav.device, dtype=dtype)
+    plain = torch.empty(B, m, 128, device=wav.device, dtype=torch.float32) if want_plain else None
+    L.check(L.load().tdc_fbank(_ptr(wav), 1 if wav.dtype == torch.float32 else 0, n, wav.stride(0), B, _ptr(window),
+                               _ptr(tw), _ptr(banks), _ptr(rng), _ptr(plain) if plain is not None else None,
+                               _ptr(patches), 256, _dtcode(dtype), mean, 1.0 / (2.0 * std), _stream()), "tdc_fbank")
+    return patches, plain, m
+
+
+def relpos_gate(q, rows, heads, head_dim, w2, b2, grep_a, out=None):
+    """q: [rows, ld] 16-bit view (un-scaled q_proj output) -> gate fp32 [rows, heads]."""
+    assert q.is_cuda and q.dim() == 2 and q.stride(1) == 1 and q.shape[0] >= rows and q.shape[1] >= heads * head_dim
+    for t, n in ((w2, 2 * head_dim), (b2, 2), (grep_a, heads)):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n
+    if out is None:
+        out = torch.empty(rows, heads, device=q.device, dtype=torch.float32)
+    L.check(L.load().tdc_relpos_gate(_ptr(q), q.stride(0), rows, heads, head_dim, _ptr(w2), _ptr(b2), _ptr(grep_a),
+                                     _ptr(out), out.stride(0), _dt(q), _stream()), "tdc_relpos_gate")
+    return out
