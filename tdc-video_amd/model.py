@@ -199,6 +199,43 @@ def build_vision_tower_aux_list(config, tower_archs=None, **kwargs):
     return out
 
 
+class BeatsHandle:
+    """stands where the reference keeps `audio_encoder.beats` (a BEATs nn.Module): checkpoint cfg + state dict; the
+    compute lives in beats.BeatsEncoder."""
+
+    def __init__(self, cfg, state):
+        self.cfg = dict(cfg) if not hasattr(cfg, "__dict__") or isinstance(cfg, dict) else dict(cfg.__dict__)
+        self.state = state
+        self._enc = None
+
+    def state_dict(self):
+        return self.state
+
+    def extract_features(self, source, padding_mask=None, feature_only=True, device=None, dtype=torch.float16):
+        """BEATs.extract_features(..., feature_only=True) (BEATs.py:131-178) -> (features, padding_mask)."""
+        if not feature_only:
+            raise NotImplementedError("the AS2M classifier head is not on the path")
+        if self._enc is None:
+            from .beats import BeatsEncoder
+            self._enc = BeatsEncoder(self.state, self.cfg, dtype=dtype,
+                                     device=device or ("cuda:%d" % torch.cuda.current_device()))
+        return self._enc.extract_features(source, padding_mask), padding_mask
+
+
+class AudioEncoderHandle:
+    """tdc/audio_models/audio_encoder.py:20-70 reduced to what the path uses: `.beats_path`, `.beats`."""
+
+    def __init__(self, beats_path="", beats_ckpt=None):
+        self.beats_path = beats_path
+        self.beats = None
+        if beats_ckpt is None and beats_path:
+            import os
+            if os.path.exists(beats_path):
+                beats_ckpt = torch.load(beats_path, map_location="cpu")
+        if beats_ckpt is not None:
+            self.beats = BeatsHandle(beats_ckpt["cfg"], beats_ckpt["model"])
+
+
 class CambrianMetaModel:
     """Mixin placed before the HF base model in the MRO (tdc/cambrian_arch.py:47-181)."""
 
@@ -245,12 +282,27 @@ class CambrianMetaModel:
     def initialize_vision_modules(self, model_args, fsdp=None):
         raise NotImplementedError("training-time module initialisation (tdc/cambrian_arch.py:206-401) is out of scope")
 
-    def initialize_audio(self, model_args):
-        """tdc/cambrian_arch.py:451-467: the BEATs encoder itself is not part of this build; audio tokens are passed in
-        as `audios=[{'audio_tokens': [T,50,768]}]`."""
+    def initialize_audio(self, model_args=None, beats_path="./checkpoints/audio_encoder/BEATs/"
+                         "BEATs_iter3_plus_AS2M_finetuned_on_AS2M_cpt2.pt", beats_ckpt=None):
+        """tdc/cambrian_arch.py:451-467: `audio_proj` + the BEATs half of AudioEncoder (audio_encoder.py:60-70; the
+        Whisper / speech-Q-Former half is commented out in the reference).  `beats_ckpt` = {'cfg': ..., 'model': state
+        dict} (what torch.load(beats_path) returns) may be passed directly."""
         if not hasattr(self, "audio_proj"):
             self.audio_proj = ParamTree({"weight": (self.config.hidden_size, 768), "bias": (self.config.hidden_size,)})
-        return None
+        self.audio_encoder = AudioEncoderHandle(beats_path, beats_ckpt)
+        self._tdc_beats = None
+        return self.audio_encoder
+
+    def tdc_beats(self, device=None, dtype=None):
+        """BeatsEncoder built (once) from audio_encoder.beats' checkpoint; None when no audio encoder is attached."""
+        ae = getattr(self, "audio_encoder", None)
+        if ae is None or ae.beats is None:
+            return None
+        if getattr(self, "_tdc_beats", None) is None:
+            from .beats import BeatsEncoder
+            eng = self.tdc_engine()
+            self._tdc_beats = BeatsEncoder(ae.beats.state, ae.beats.cfg, dtype=dtype or eng.dtype, device=device or eng.dev)
+        return self._tdc_beats
 
     def initialize_compressor(self, config, pretrained_qformer=None, context_token_num=16):
         """tdc/cambrian_arch.py:469-484 (+ init_Qformer :403-424): bert-base Q-Former with cross-attention to the LLM
@@ -420,6 +472,10 @@ class CambrianMetaForCausalLM(ABC):
                 audio = audios[i]
                 if not isinstance(audio, dict):
                     audio = {"audio_tokens": audio.to(eng.dev)}
+                elif audio.get("audio_wav") is not None and audio.get("beats_windows") is None \
+                        and audio.get("audio_tokens") is None:
+                    # the reference's own audio dict (cambrian_arch.py:1547): raw waveform -> BEATs on the device
+                    eng.beats = model.tdc_beats()
             keep = {}
             if is_video:
                 # a21 hand-off: when embed_tokens lives on the engine device in the engine dtype the

@@ -43,6 +43,7 @@ class VideoEncoder:
         self.two_streams = False
         self.native_qformer = True    # Q-Former through the C++ composite tdc_qformer_fwd
         self.native_towers = True     # towers through the C++ composite tdc_vit_fwd (per-kernel Python path when False)
+        self.beats = None             # beats.BeatsEncoder for raw-waveform audio input
 
     # ------------------------------------------------------------------------------------------------ towers
     def _bil(self, n_in, n_out):
@@ -313,6 +314,15 @@ class VideoEncoder:
             out[i] = x[:, :Da]
         return out
 
+    def beats_windows(self, wav, mask=None):
+        """tdc/cambrian_arch.py:1552-1560: BEATs features of the consecutive 10-s windows of wav [1, n] (16 kHz).
+        `self.beats` is a beats.BeatsEncoder (set by the owner of the weights, e.g. model.initialize_audio)."""
+        if getattr(self, "beats", None) is None:
+            raise RuntimeError("raw audio given but no BEATs encoder is attached (VideoEncoder.beats)")
+        if mask is not None and bool(torch.as_tensor(mask).bool().any()):
+            raise NotImplementedError("padded audio (audio_wav_mask with True entries)")
+        return self.beats.window_features(wav)
+
     def with_audio(self, X, T, N, audio):
         """a20: frames become [visual N | audio_proj(audio) Na] rows (tdc/cambrian_arch.py:1611-1614)."""
         c, dt, dev = self.c, self.dtype, self.dev
@@ -521,7 +531,10 @@ def encode_video_with(e, px_siglip, px_dino, image_size, budget_text_len, n_text
             samp = [0] * T0
             for i in idx:
                 samp[i] = 1
-            audio = e.audio_tokens(audio["beats_windows"], samp, T)
+            wins = audio.get("beats_windows")
+            if wins is None:                                   # raw 16 kHz waveform: BEATs on the device (8(f)-1)
+                wins = e.beats_windows(audio["audio_wav"], audio.get("audio_wav_mask"))
+            audio = e.audio_tokens(wins, samp, T)
     vis = compress_with(e, X, T, N, seg_idx, pid, max_visual_len, audio, keep, splice)              # a11-a19 (+a21)
     if keep is not None:
         keep.update(frame_indices=idx, selected=sel2, seg_indices=seg_idx, siglip_feat=sig, dino_feat=dino,

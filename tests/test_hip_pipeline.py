@@ -344,6 +344,56 @@ def test_full_pipeline_audio_vs_golden(dtype):
     assert rel(full, ref) < stage_tol(dtype)
 
 
+def test_raw_waveform_audio_through_beats_vs_oracle():
+    """SURVEY 8(f)-1 end to end: audio={"audio_wav": wav} -> BEATs on the device (beats.BeatsEncoder) -> a20 -> emitted
+    tokens, against the oracle chain (beats_oracle.window_features -> tdc_oracle.encode_video)."""
+    import beats_oracle as BO
+    from tdc_video_amd.beats import BeatsEncoder
+    W, o = load_fixture("pipeline_T40_audio.npz")
+    cfg = pipeline_cfg(o)
+    enc = make_encoder(W, cfg, torch.float16)
+    bcfg = dict(BO.BEATS_ITER3_CFG, embed_dim=64, encoder_layers=2, encoder_ffn_embed_dim=256, conv_pos=16,
+                num_buckets=64, max_distance=200)
+    g = torch.Generator().manual_seed(31)
+    rn = lambda *s, std=0.05: torch.randn(*s, generator=g) * std
+    C, E = 768, 64
+    BW = {"patch_embedding.weight": rn(E, 1, 16, 16, std=0.06), "layer_norm.weight": 1 + rn(E), "layer_norm.bias": rn(E),
+          "post_extract_proj.weight": rn(C, E, std=0.1), "post_extract_proj.bias": rn(C),
+          "encoder.pos_conv.0.weight_g": 1 + rn(1, 1, 16).abs(), "encoder.pos_conv.0.weight_v": rn(C, C // 16, 16),
+          "encoder.pos_conv.0.bias": rn(C), "encoder.layer_norm.weight": 1 + rn(C), "encoder.layer_norm.bias": rn(C)}
+    emb = rn(64, 12, std=1.0)
+    for i in range(2):
+        p = "encoder.layers.%d." % i
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            BW[p + "self_attn." + n + ".weight"], BW[p + "self_attn." + n + ".bias"] = rn(C, C, std=0.04), rn(C)
+        BW[p + "self_attn.grep_linear.weight"], BW[p + "self_attn.grep_linear.bias"] = rn(8, 64, std=0.2), rn(8, std=0.2)
+        BW[p + "self_attn.grep_a"] = 1 + rn(1, 12, 1, 1, std=0.2)
+        BW[p + "self_attn.relative_attention_bias.weight"] = emb
+        BW[p + "fc1.weight"], BW[p + "fc1.bias"] = rn(256, C, std=0.04), rn(256)
+        BW[p + "fc2.weight"], BW[p + "fc2.bias"] = rn(C, 256, std=0.06), rn(C)
+        for n in ("self_attn_layer_norm", "final_layer_norm"):
+            BW[p + n + ".weight"], BW[p + n + ".bias"] = 1 + rn(C), rn(C)
+    enc.beats = BeatsEncoder(BW, bcfg, dtype=torch.float16, device="cuda:0")
+    wav = torch.from_numpy(o["audio_wav"].astype(np.float32))
+    vid = torch.from_numpy(synth.video_from_basis(o["video_basis"], o["video_coef"]))
+    ids = torch.from_numpy(o["input_ids"])
+    size = tuple(int(v) for v in o["image_size"])
+    pid = [int(i) for i in o["prompt_ids"]]
+    vis = enc.encode_video(vid.cuda(), (vid + 0.01).cuda(), size, budget_text_len=ids.shape[1], n_text_tokens=ids.shape[1] - 1,
+                           prompt_ids=pid, audio={"audio_wav": wav.half(), "audio_wav_mask": torch.zeros_like(wav).half()})
+    with pytest.raises(RuntimeError):
+        make_encoder(W, cfg, torch.float16).encode_video(vid.cuda(), vid.cuda(), size, ids.shape[1], ids.shape[1] - 1, pid,
+                                                         audio={"audio_wav": wav})
+    W2 = dict(W)
+    W2["embed_tokens_fn"] = embed_fn(o)
+    wins = BO.window_features(BW, bcfg, wav.half().float())
+    r = oracle.encode_video(W2, cfg, vid, vid + 0.01, size, ids, pid, beats_windows=wins)
+    pos = int(torch.where(ids[0] == -200)[0][0])
+    ref = r["inputs_embeds"][0][pos:pos + vis.shape[0]]
+    assert vis.shape[0] == r["inputs_embeds"].shape[1] - (ids.shape[1] - 1)
+    assert rel(vis, ref) < stage_tol(torch.float16)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_native_tower_composite_equals_kernel_sequence(dtype):
     """tdc_vit_fwd (C++ composite) launches the same kernels as the per-kernel Python sequence: bit-identical output."""
