@@ -280,10 +280,15 @@ def main():
     # HBM-side traffic per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction), collected on the
     # same GEMM launch list by the torch-free driver tools/gemm_pmc.cpp (rocprofv3 --pmc segfaults inside a torch
     # process on this image) and committed under profiles/; null when that summary is absent or another workload runs.
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_gemm_pmc_summary.json")
-    if os.path.exists(pmc) and (T, K, H) == (512, 144, 3584):
-        traffic = round(json.load(open(pmc))["per_launch_hbm_bytes"])
+    traffic = mfma_busy = kv_busy = None
+    pmc = os.path.join(ROOT, "profiles", "r01c_gemm_pmc_summary.json")
+    if os.path.exists(pmc) and (T, K, H, world, args.tower_batch) == (512, 144, 3584, 1, 256):
+        summ = json.load(open(pmc))
+        traffic = round(summ["per_launch_hbm_bytes"])
+        # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles) over the same launch list: MFMA pipe occupancy at the
+        # clock the chip actually holds (it drops to ~1.9 GHz under this load, so this reads higher than `frac`)
+        mfma_busy = summ.get("mfma_busy_frac")
+        kv_busy = max((r.get("mfma_busy_frac", 0) for r in summ["shapes"] if r["N"] >= 9216 and r["K"] == H), default=None)
     roofline = dict(bound="mfma", achieved=round(achieved, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(achieved / MFMA_PEAK_TFLOPS, 4), traffic=traffic,
                     kernel="gemm256_kernel / gemm_kernel (tdc_gemm)",
@@ -293,7 +298,7 @@ def main():
                                    tflops=round(a_fl / (a_ms * 1e-3) / 1e12, 1) if a_ms > 0 else None,
                                    launches=len(prof["attn"])),
                     xattn_kv_gemm_tflops=round(sum(w for _, w in kv) / (sum(t for t, _ in kv) * 1e-3) / 1e12, 1)
-                    if kv else None)
+                    if kv else None, mfma_busy_pmc=mfma_busy, xattn_kv_mfma_busy_pmc=kv_busy)
     if rank != 0:
         return
     res = {

@@ -19,19 +19,36 @@ def per_dispatch(counter):
 
 fetch, write = per_dispatch("FETCH_SIZE"), per_dispatch("WRITE_SIZE")
 assert len(fetch) == len(shapes) == len(write), (len(fetch), len(write), len(shapes))
+try:    # MFMA pipe occupancy: busy cycles summed over the 1024 SIMDs / (1024 x kernel cycles); GRBM_GUI_ACTIVE is summed
+    # over the 8 XCDs (MI355X_MICROARCH.md, DVFS).  16 busy cycles per v_mfma_f32_16x16x32 (its pipe time).
+    mfma, gui = per_dispatch("SQ_VALU_MFMA_BUSY_CYCLES"), per_dispatch("GRBM_GUI_ACTIVE")
+    assert len(mfma) == len(gui) == len(shapes)
+except Exception as e:  # noqa: BLE001
+    print("no MFMA-busy pass:", e)
+    mfma = gui = None
 tot_traffic = tot_alg = tot_n = 0.0
 res = []
 for (M, N, K, act, has_res, of32, count), fk, wk in zip(shapes, fetch, write):
     traffic = (2.0 * fk + wk) * 1024.0
     n_out = N // 2 if act == 3 else N
     alg = 2.0 * (M * K + N * K) + M * n_out * (4 if of32 else 2) * (2 if has_res else 1)
-    res.append(dict(M=M, N=N, K=K, act=act, res=has_res, out_f32=of32, launches_per_step=count,
-                    hbm_bytes=traffic, algorithmic_bytes=alg, ratio=round(traffic / alg, 3)))
+    row = dict(M=M, N=N, K=K, act=act, res=has_res, out_f32=of32, launches_per_step=count,
+               hbm_bytes=traffic, algorithmic_bytes=alg, ratio=round(traffic / alg, 3))
+    if mfma is not None:
+        i = len(res)
+        cyc = gui[i] / 8.0
+        row.update(mfma_busy_cycles=mfma[i], kernel_cycles=cyc, mfma_busy_frac=round(mfma[i] / (1024.0 * cyc), 4),
+                   mfma_busy_expected=16.0 * (2.0 * M * N * K / 16384.0))
+        mf_b = locals().get("mf_b", 0.0) + mfma[i] * count
+        mf_c = locals().get("mf_c", 0.0) + 1024.0 * cyc * count
+    res.append(row)
     tot_traffic += traffic * count
     tot_alg += alg * count
     tot_n += count
 summary = dict(per_launch_hbm_bytes=tot_traffic / tot_n, per_launch_algorithmic_bytes=tot_alg / tot_n,
                ratio=round(tot_traffic / tot_alg, 3), launches_per_step=int(tot_n), shapes=res)
+if mfma is not None:
+    summary["mfma_busy_frac"] = round(mf_b / mf_c, 4)
 json.dump(summary, open(out + "/gemm_pmc_summary.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in summary.items() if k != "shapes"}))
 for r in res[:12]:
