@@ -176,7 +176,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--px", type=int, default=384, help="SigLIP input size (DINO uses px-6: 378); 336 -> 336/336")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--tower-batch", type=int, default=256)
+    ap.add_argument("--tower-batch", type=int, default=512)
     ap.add_argument("--two-streams", type=int, default=0, help="run the two towers on two HIP streams")
     ap.add_argument("--dump-gemm-shapes", default=None, help="write the GEMM launches of one step (for tools/gemm_pmc)")
     args = ap.parse_args()
@@ -282,7 +282,7 @@ def main():
     # process on this image) and committed under profiles/; null when that summary is absent or another workload runs.
     traffic = mfma_busy = kv_busy = None
     pmc = os.path.join(ROOT, "profiles", "r01c_gemm_pmc_summary.json")
-    if os.path.exists(pmc) and (T, K, H, world, args.tower_batch) == (512, 144, 3584, 1, 256):
+    if os.path.exists(pmc) and (T, K, H, world, args.tower_batch) == (512, 144, 3584, 1, 512):
         summ = json.load(open(pmc))
         traffic = round(summ["per_launch_hbm_bytes"])
         # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles) over the same launch list: MFMA pipe occupancy at the
