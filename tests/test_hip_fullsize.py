@@ -118,3 +118,94 @@ def test_sharded_world1_equals_serial_fullsize(full):
     finally:
         dist.destroy_process_group()
     assert torch.equal(got, want)
+
+
+# ---- full-size NUMERIC parity against the oracle on bounded samples (the GPU box's host cores run the fp32 restatement:
+#      2 frames through both towers, connector + compressor on a 32-frame clip; about a minute) -----------------------
+def _oracle():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import tdc_oracle
+    return tdc_oracle
+
+
+def _rel(a, b):
+    return float((a.float().cpu() - b.float().cpu()).abs().max()) / max(1e-6, float(b.abs().max()))
+
+
+@pytest.fixture(scope="module")
+def full_sd():
+    import bench
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(0)
+    H, K, T = 3584, 144, 40
+    sd = bench.random_state_dict(H, K, dev, gen)
+    return {k: v.float().cpu() for k, v in sd.items()}, bench.model_cfg(H, K, T), H, K
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 8e-3), (torch.bfloat16, 6e-2)])
+def test_fullsize_towers_vs_oracle(full_sd, dtype, tol):
+    """SigLIP-so400m (27 x 1152, d_head 72) and DINOv2-giant (40 x 1536, SwiGLU, LayerScale) at full depth and width:
+    2 frames, HIP vs the fp32 oracle.  Tolerances are relative to max|ref| of the tower output: the raw residual
+    stream of a random-init 40-layer ViT is carried through 80 16-bit GEMM inputs (bf16: 8 mantissa bits)."""
+    import tdc_video_amd  # noqa: F401
+    from tdc_video_amd.pipeline import VideoEncoder
+    orc = _oracle()
+    sd, cfg, H, K = full_sd
+    enc = VideoEncoder(sd, cfg, dtype=dtype, device="cuda:0", tower_batch=2)
+    g = torch.Generator().manual_seed(5)
+    xs = torch.rand(2, 3, 384, 384, generator=g) * 2 - 1
+    xd = torch.rand(2, 3, 378, 378, generator=g) * 2 - 1
+    Ws = {k[len("vision_tower_aux_list.0.vision_tower."):]: v for k, v in sd.items() if k.startswith("vision_tower_aux_list.0.")}
+    Wd = {k[len("vision_tower_aux_list.1.vision_tower."):]: v for k, v in sd.items() if k.startswith("vision_tower_aux_list.1.")}
+    with torch.no_grad():
+        ref_s, _ = orc.siglip_tower(xs, Ws, 16)
+        ref_d, _ = orc.dino_tower(xd, Wd, 24)
+    got_s = enc.tower("siglip", xs.cuda())[:, :1152].reshape(2, 576, 1152)
+    got_d = enc.tower("dino", xd.cuda())[:, :1536].reshape(2, 576, 1536)
+    es, ed = _rel(got_s, ref_s), _rel(got_d, ref_d)
+    print("full-size tower rel err %s: siglip %.3e dino %.3e" % (dtype, es, ed))
+    assert es < tol and ed < tol, (es, ed)
+
+
+def test_fullsize_connector_compressor_vs_oracle(full_sd):
+    """S4-S10 at BASELINE sizes (C=1024, H=3584, K=144, 12-layer Q-Former) on a 32-frame clip of tower features:
+    emitted tokens vs the oracle; compressed (unit-norm) rows within the north_star's 1e-3 fp16 atol."""
+    import tdc_video_amd  # noqa: F401
+    from tdc_video_amd.pipeline import VideoEncoder
+    from tdc_video_amd import segment as seg
+    orc = _oracle()
+    sd, cfg, H, K = full_sd
+    W = {k: v for k, v in sd.items() if not k.startswith("vision_tower_aux_list")}
+    enc = VideoEncoder(W, cfg, dtype=torch.float16, device="cuda:0")
+    T = 32
+    g = torch.Generator().manual_seed(9)
+    sig = torch.randn(T, 576, 1152, generator=g).half().float()
+    din = torch.randn(T, 576, 1536, generator=g).half().float()
+    pid = [101] + list(range(2000, 2010)) + [102]
+    with torch.no_grad():
+        aux = [orc.mm_projector_aux(sig, W, 0), orc.mm_projector_aux(din, W, 1)]
+        q, _ = orc.sva(aux, W["vision_query"][0], [(384, 384)] * T, W, 12)
+        feat = orc.mm_projector(q, W)
+        frames, _ = orc.unpad_newline(feat, [(384, 384)] * T, W["image_newline"])
+        segi = orc.select_segments(orc.adjacent_cosine(din), 24)
+        want = orc.tdc_compress(torch.stack(frames), segi, torch.tensor(pid), W, K, 12, 10 ** 9)
+    from tdc_video_amd.weights import pad64
+    def pad(x, D):
+        buf = torch.zeros(x.shape[0] * x.shape[1], pad64(D), dtype=torch.float16, device="cuda:0")
+        buf[:, :D] = x.reshape(-1, D).half().cuda()
+        return buf
+    keep = {}
+    X, _ = enc.connector(pad(sig, 1152), pad(din, 1536), T, [(384, 384)] * T, keep)
+    sims = enc.sims_tensor(pad(din, 1536), T).tolist()
+    assert seg.select_segments(sims, 24) == [int(i) for i in segi]
+    got = enc.compress(X, T, X.shape[0] // T, [int(i) for i in segi], pid, 10 ** 9, keep=keep)
+    assert tuple(got.shape) == tuple(want.shape)
+    plan = keep["plan"]
+    comp_rows = [i for i, e in enumerate(plan["src"]) if e[0] == "c"]
+    stat_rows = [i for i, e in enumerate(plan["src"]) if e[0] == "f"]
+    assert len(comp_rows) == len(plan["comp_frames"]) * K and comp_rows
+    err_c = float((got[comp_rows].float().cpu() - want[comp_rows]).abs().max())
+    err_s = _rel(got[stat_rows], want[stat_rows])
+    print("full-size compressed-token max abs err %.3e (unit-norm rows), static rows rel %.3e" % (err_c, err_s))
+    assert err_c < 1e-3, err_c
+    assert err_s < 4e-3, err_s
