@@ -178,6 +178,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tower-batch", type=int, default=512)
     ap.add_argument("--two-streams", type=int, default=0, help="run the two towers on two HIP streams")
+    ap.add_argument("--audio", action="store_true", help="BASELINE config 4: + T seconds of 16 kHz audio through BEATs "
+                    "on the device, 50 audio tokens per frame in the Q-Former KV (1 GPU only)")
     ap.add_argument("--dump-gemm-shapes", default=None, help="write the GEMM launches of one step (for tools/gemm_pmc)")
     args = ap.parse_args()
 
@@ -213,6 +215,18 @@ def main():
     enc = VideoEncoder(sd, cfg, dtype=dtype, device=dev, siglip_heads=16, dino_heads=24, qformer_heads=12,
                        tower_batch=args.tower_batch)
     enc.two_streams = bool(args.two_streams)
+    wav = None
+    if args.audio:
+        assert world == 1, "--audio: single-GPU workload"
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from bench_beats import random_beats_state
+        from tdc_video_amd.beats import BEATS_ITER3_CFG, BeatsEncoder
+        from tdc_video_amd import weights as Wt
+        enc.cfg["audio_input"] = True
+        enc.c.audio_proj = Wt.make_lin(torch.randn(H, 768, device=dev, generator=gen) * 0.02,
+                                       torch.zeros(H, device=dev), dtype, dev)
+        enc.beats = BeatsEncoder(random_beats_state(BEATS_ITER3_CFG), BEATS_ITER3_CFG, dtype=dtype, device=dev)
+        wav = (0.1 * torch.randn(1, 16000 * T, device=dev, generator=gen)).half()      # 1 frame per second
     sd_cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sd_cpu = {k: v.cpu() for k, v in sd.items()}
@@ -227,7 +241,7 @@ def main():
 
         def step():
             return enc.encode_video(vs, vd, (384, 384), budget_text_len=64, n_text_tokens=64, prompt_ids=prompt_ids,
-                                    frame_cap=T)
+                                    frame_cap=T, audio={"audio_wav": wav} if wav is not None else None)
     else:
         from tdc_video_amd import dist as tdist
         halo = 1 if rank < world - 1 else 0
@@ -308,7 +322,9 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "one %d-frame video, SigLIP-so400m/14@%d + DINOv2-giant/14@%d towers (729 patches -> 576 "
                                "tokens), SVA 576->144, mm_projector -> H=%d, Q-Former TDC K=%d (N=156, 12 prompt ids), "
-                               "random-init weights, frame cap lifted to T, LLM stubbed" % (T, px_s, px_d, H, K),
+                               "random-init weights, frame cap lifted to T, LLM stubbed%s"
+                               % (T, px_s, px_d, H, K, ", + %d s of 16 kHz audio through BEATs (50 audio tokens / frame in "
+                                  "the Q-Former KV)" % T if args.audio else ""),
                    "frames": T, "K": K, "hidden": H, "parallelism": "frames sharded over %d GPU(s)" % world,
                    "emitted_tokens": int(out.shape[0])},
         "roofline": roofline,

@@ -209,3 +209,38 @@ def test_fullsize_connector_compressor_vs_oracle(full_sd):
     print("full-size compressed-token max abs err %.3e (unit-norm rows), static rows rel %.3e" % (err_c, err_s))
     assert err_c < 1e-3, err_c
     assert err_s < 4e-3, err_s
+
+
+def test_fullsize_video_plus_audio_token_accounting(full):
+    """BASELINE config 4 at full sizes: T seconds of audio through BEATs (released dimensions) + a20 interleave: the
+    Q-Former KV grows to N + 50 rows per frame, static frames emit N + 50 + 1 tokens, compressed frames K + 1
+    (SURVEY appendix B); bitwise reproducible."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_beats import random_beats_state
+    from tdc_video_amd import weights as Wt
+    from tdc_video_amd.beats import BEATS_ITER3_CFG, BeatsEncoder
+    enc, vs, vd, T, K, H = full
+    dev = vs.device
+    g = torch.Generator(device=dev).manual_seed(3)
+    old = (enc.cfg.get("audio_input"), enc.c.audio_proj, enc.beats)
+    try:
+        enc.cfg["audio_input"] = True
+        enc.c.audio_proj = Wt.make_lin(torch.randn(H, 768, device=dev, generator=g) * 0.02, torch.zeros(H, device=dev),
+                                       torch.bfloat16, dev)
+        enc.beats = BeatsEncoder(random_beats_state(BEATS_ITER3_CFG), BEATS_ITER3_CFG, dtype=torch.bfloat16, device=dev)
+        wav = (0.1 * torch.randn(1, 16000 * T + 4321, device=dev, generator=g)).half()
+        keep = {}
+        a = run(enc, vs, vd, keep, audio={"audio_wav": wav, "audio_wav_mask": torch.zeros_like(wav)})
+        b = run(enc, vs, vd, audio={"audio_wav": wav})
+        assert torch.equal(a, b)
+        plan = keep["plan"]
+        N = 156
+        n_static = len(plan["chunks"])
+        n_comp = len(plan["comp_frames"])
+        assert n_static + n_comp == T and n_comp > 0
+        assert a.shape[0] == n_static * (N + 50 + 1) + n_comp * (K + 1)
+        assert torch.isfinite(a.float()).all()
+    finally:
+        enc.cfg["audio_input"], enc.c.audio_proj, enc.beats = old
+        if old[0] is None:
+            enc.cfg.pop("audio_input", None)
