@@ -427,15 +427,21 @@ def qformer_bert(query_embeds, enc, prompt_ids, W, heads, p="Qformer.bert.", eps
     return x
 
 
-def compress_chunk(chunk, prompt_ids, W, K, heads, audio_chunk=None):
+def compress_chunk(chunk, prompt_ids, W, K, heads, audio_chunk=None, add_static=True, query_type="Avg_pool"):
     """One <=8-frame chunk (tdc/cambrian_arch.py:1608-1667): key = chunk[0]; returns compressed [L,K,H] (L2-normalised)
-    and the chunk features actually used (with audio tokens appended when given, :1611-1614)."""
+    and the chunk features actually used (with audio tokens appended when given, :1611-1614).  add_static=False: the
+    key frame itself is compressed too (:1625-1628); query_type='learned': query_tokens instead of the pooled key
+    frame (:1633-1640)."""
     key = chunk[0]  # visual-only key frame (:1609) - pooled BEFORE the audio concat
     if audio_chunk is not None:
         chunk = torch.cat([chunk, _lin(audio_chunk, W, "audio_proj")], dim=1)
-    L = chunk.shape[0] - 1
-    q = _lin(adaptive_avg_pool_tokens(key, K), W, "query_proj")  # [K, Dq]
-    last = qformer_bert(q[None].expand(L, -1, -1), chunk[1:], prompt_ids, W, heads)
+    vin = chunk[1:] if add_static else chunk
+    L = vin.shape[0]
+    if query_type == "learned":
+        q = W["query_tokens"][0]
+    else:
+        q = _lin(adaptive_avg_pool_tokens(key, K), W, "query_proj")  # [K, Dq]
+    last = qformer_bert(q[None].expand(L, -1, -1), vin, prompt_ids, W, heads)
     comp = F.normalize(_lin(last[:, :K], W, "vision_proj"), dim=-1)
     return comp, chunk
 
@@ -485,25 +491,27 @@ def chunk_table(T, seg_indices):
     return chunks
 
 
-def tdc_compress(frames, seg_indices, prompt_ids, W, K, heads, max_visual_len, audio=None):
+def tdc_compress(frames, seg_indices, prompt_ids, W, K, heads, max_visual_len, audio=None, add_static=True,
+                 query_type="Avg_pool"):
     """S10 (tdc/cambrian_arch.py:1520-1709): frames [T,N,H] -> emitted visual tokens [n,H].
-    add_static=True, add_sep=True, query_type='Avg_pool', text_input per prompt_ids (None = no text)."""
+    add_sep=True (hard-wired at :1512); add_static / query_type per config (:1509-1511); text_input per prompt_ids
+    (None = no text)."""
     T = frames.shape[0]
     fseg = W["frame_seg"][None]
     out = []
     for (s, e) in chunk_table(T, seg_indices):
         chunk = frames[s:e]
         ach = audio[s:e] if audio is not None else None
-        if e - s == 1:
+        if add_static and e - s == 1:
             c0 = chunk[0]
             if ach is not None:
                 c0 = torch.cat([c0, _lin(ach[0], W, "audio_proj")], dim=0)
             out.append(torch.cat([c0, fseg]))
             continue
-        comp, chunk_full = compress_chunk(chunk, prompt_ids, W, K, heads, ach)
+        comp, chunk_full = compress_chunk(chunk, prompt_ids, W, K, heads, ach, add_static, query_type)
         L = comp.shape[0]
-        out.append(torch.cat([torch.cat([chunk_full[0], fseg]),
-                              torch.cat([comp, fseg[None].expand(L, -1, -1)], dim=1).flatten(0, 1)], dim=0))
+        ctx = torch.cat([comp, fseg[None].expand(L, -1, -1)], dim=1).flatten(0, 1)
+        out.append(torch.cat([torch.cat([chunk_full[0], fseg]), ctx], dim=0) if add_static else ctx)
     total = sum(x.shape[0] for x in out)
     if total > max_visual_len:
         rm = math.ceil((total - max_visual_len) / len(out))
@@ -557,7 +565,8 @@ def encode_video(W, cfg, px_siglip, px_dino, image_size, input_ids, prompt_ids, 
         audio = audio_tokens(beats_windows, samp, T)                                                  # a20
         r["audio_tokens"] = audio
     vis = tdc_compress(frames, seg, prompt_ids if cfg.get("text_input", True) else None, W,
-                       cfg.get("context_token_num", 16), cfg["qformer_heads"], max_visual_len, audio)  # a11-a20
+                       cfg.get("context_token_num", 16), cfg["qformer_heads"], max_visual_len, audio,
+                       cfg.get("add_static", True), cfg.get("query_type", "Avg_pool"))                 # a11-a20
     r["visual_tokens"] = vis
     x = torch.cat([emb(pre), vis, emb(post)], dim=0)[: cfg["tokenizer_model_max_length"]]
     r["inputs_embeds"] = x[None]

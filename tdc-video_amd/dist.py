@@ -91,7 +91,9 @@ class ShardedVideoEncoder:
         K = e.K
         # 3. shared plan, query hand-off
         max_visual_len = cfg["tokenizer_model_max_length"] - cfg.get("inference_max_length", 16) - n_text_tokens
-        plan = seg.emit_plan(T, N, K, seg_idx, max_visual_len)
+        if cfg.get("query_type", "Avg_pool") != "Avg_pool":
+            raise NotImplementedError("frame sharding implements the default query_type='Avg_pool' hand-off only")
+        plan = seg.emit_plan(T, N, K, seg_idx, max_visual_len, cfg.get("add_static", True))
         pairs, comp_local = split_plan(plan, ranges, N, K)
         keys = plan["key_frames"]
         my_comp = [gi for gi, f in enumerate(plan["comp_frames"]) if lo <= f < hi]

@@ -388,7 +388,7 @@ class CambrianMetaForCausalLM(ABC):
     def _cfg(self):
         c = self.get_model().config
         keys = ("context_token_num", "audio_input", "add_static", "tokenizer_model_max_length", "inference_max_length",
-                "max_num_segments", "text_input")
+                "max_num_segments", "text_input", "query_type")
         d = {k: getattr(c, k) for k in keys if hasattr(c, k)}
         return d
 

@@ -344,6 +344,13 @@ class VideoEncoder:
         pooled = ops.adaptive_pool_tokens(Xf, N, self.K, len(key_rows), keys, frame_rows=Nf)
         return ops.gemm(pooled, self.c.query_proj.w, self.c.query_proj.b)
 
+    def learned_queries(self):
+        """query_type == 'learned' (tdc/cambrian_arch.py:1639-1640): `query_tokens` [1, K, Dq] -> [K, Dq_pad] 16-bit."""
+        qt = self.c.query_tokens
+        if qt is None:
+            raise RuntimeError("query_type='learned' needs `query_tokens` in the state dict")
+        return qt
+
     def _qformer_struct(self):
         """ctypes mirror of tdc_qformer_model (cached)."""
         if getattr(self, "_qf_struct", None) is not None:
@@ -459,12 +466,16 @@ class VideoEncoder:
 # implements tower / sims_tensor / connector / with_audio / make_queries / compress_frames / emit / query_width).
 def compress_with(e, X, T, N, seg_indices, prompt_ids, max_visual_len, audio=None, keep=None, splice=None):
     K = e.K
+    cfg = getattr(e, "cfg", {})
     Xf, Nf = e.with_audio(X, T, N, audio)
-    plan = seg.emit_plan(T, Nf, K, seg_indices, max_visual_len)
+    plan = seg.emit_plan(T, Nf, K, seg_indices, max_visual_len, cfg.get("add_static", True))
     comp = None
     if plan["comp_frames"]:
-        qtable = e.make_queries(Xf, N, Nf, plan["key_frames"])
-        comp = e.compress_frames(Xf, Nf, plan["comp_frames"], qtable, plan["comp_chunk"], prompt_ids, keep)
+        if cfg.get("query_type", "Avg_pool") == "learned":      # cambrian_arch.py:1639-1640: one shared query block
+            qtable, qsrc = e.learned_queries(), [0] * len(plan["comp_frames"])
+        else:
+            qtable, qsrc = e.make_queries(Xf, N, Nf, plan["key_frames"]), plan["comp_chunk"]
+        comp = e.compress_frames(Xf, Nf, plan["comp_frames"], qtable, qsrc, prompt_ids, keep)
     pairs = []
     for en in plan["src"]:
         if en[0] == "f":

@@ -95,23 +95,25 @@ def unpad_newline_map(side, image_size, frame, newline_table=1, newline_row=0, f
     return src, (r1 - r0, c1 - c0)
 
 
-def emit_plan(T, N, K, seg_indices, max_visual_len):
-    """Token layout of tdc/cambrian_arch.py:1603-1709 (add_static, add_sep): returns
+def emit_plan(T, N, K, seg_indices, max_visual_len, add_static=True):
+    """Token layout of tdc/cambrian_arch.py:1603-1709 (add_sep is hard-wired True at :1512): returns
        chunks          [(start,end)]
        comp_frames     frame index of every compressed frame, in emission order
-       comp_chunk      for each compressed frame the index (among multi-frame chunks) of its chunk
-       key_frames      key frame index of every multi-frame chunk
+       comp_chunk      for each compressed frame the index (among chunks that run the Q-Former) of its chunk
+       key_frames      key frame index of every chunk that runs the Q-Former
        src             list of (kind, a, b): ('f', frame, tok) static token, ('c', comp_idx, k) context token, ('s',)
-                        frame separator - after the per-chunk tail clipping and the final [:max_visual_len] cut."""
+                        frame separator - after the per-chunk tail clipping and the final [:max_visual_len] cut.
+    add_static=False (:1625-1628, :1686-1690): no static tokens; every frame of every chunk, the key frame and
+    single-frame chunks included, is compressed."""
     chunks = chunk_table(T, seg_indices)
     comp_frames, comp_chunk, key_frames = [], [], []
     per_chunk = []
     for (s, e) in chunks:
-        toks = [("f", s, t) for t in range(N)] + [("s",)]
-        if e - s > 1:
+        toks = [("f", s, t) for t in range(N)] + [("s",)] if add_static else []
+        if e - s > 1 or not add_static:
             ci = len(key_frames)
             key_frames.append(s)
-            for f in range(s + 1, e):
+            for f in range(s + 1 if add_static else s, e):
                 idx = len(comp_frames)
                 comp_frames.append(f)
                 comp_chunk.append(ci)

@@ -318,6 +318,12 @@ def prep_connector(sd, cfg, dtype, dev):
     c.qformer = q
     c.query_proj = make_lin(sd["query_proj.weight"], sd["query_proj.bias"], dtype, dev)
     c.vision_proj = make_lin(sd["vision_proj.weight"], sd["vision_proj.bias"], dtype, dev)
+    c.query_tokens = None
+    if "query_tokens" in sd:
+        qt = sd["query_tokens"].detach().reshape(-1, sd["query_tokens"].shape[-1]).to(torch.float32)
+        buf = torch.zeros(qt.shape[0], pad64(qt.shape[1]), dtype=dtype, device=qt.device)
+        buf[:, : qt.shape[1]] = qt.to(dtype)
+        c.query_tokens = buf.to(dev)
     c.audio_proj = None
     if "audio_proj.weight" in sd:
         c.audio_proj = make_lin(sd["audio_proj.weight"], sd["audio_proj.bias"], dtype, dev)

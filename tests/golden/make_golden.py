@@ -427,8 +427,25 @@ def make_preprocess():
     save("preprocess_small.npz", **arrs)
 
 
+def make_ablations():
+    """config ablations of the emission loop (tdc/cambrian_arch.py:1509-1512,1625-1640,1668-1692): add_static=False (every
+    frame, key frames included, is compressed) and query_type='learned' (query_tokens instead of pooled key frames)."""
+    man = {}
+    man["pipeline_T40_nostatic"] = run_pipeline("pipeline_T40_nostatic.npz", 40, (384, 384), "what happens in the video ?",
+                                                seed=4, cfg_over=dict(add_static=False), keep_intermediates=False)
+    man["pipeline_T40_learned"] = run_pipeline("pipeline_T40_learned.npz", 40, (384, 384), "what happens in the video ?",
+                                               seed=5, cfg_over=dict(query_type="learned"), keep_intermediates=False)
+    return man
+
+
 if __name__ == "__main__":
     import transformers
+    if len(sys.argv) > 1 and sys.argv[1] == "--ablations":   # add the ablation fixtures without touching the others
+        mp = os.path.join(HERE, "manifest.json")
+        man = json.load(open(mp))
+        man.update(make_ablations())
+        json.dump(man, open(mp, "w"), indent=1)
+        sys.exit(0)
     man = dict(torch=torch.__version__, transformers=transformers.__version__, reference="Hoar012/TDC-Video @ 2025-08-29",
                bert=BERT_KW, H_LLM=H_LLM, C_VIS=C_VIS)
     make_preprocess()
@@ -448,6 +465,7 @@ if __name__ == "__main__":
                                              # video_indices=[None] (generate()) leaves sample_indices = None and the
                                              # reference's audio loop raises TypeError at cambrian_arch.py:1562
                                              video_indices=None)
+    man.update(make_ablations())
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(man, f, indent=1)
     print(json.dumps(man, indent=1))

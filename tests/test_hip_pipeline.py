@@ -224,6 +224,30 @@ def test_full_pipeline_vs_golden(name, dtype):
         assert err < (1e-3 if dtype == torch.float16 else 8e-3), err
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name", ["pipeline_T40_nostatic.npz", "pipeline_T40_learned.npz"])
+def test_config_ablations_vs_golden(name, dtype):
+    """add_static=False / query_type='learned' (reference-generated fixtures): emitted stream vs the reference's."""
+    W, o = load_fixture(name)
+    cfg = pipeline_cfg(o)
+    enc = make_encoder(W, cfg, dtype)
+    vid = torch.from_numpy(synth.video_from_basis(o["video_basis"], o["video_coef"]))
+    ids = torch.from_numpy(o["input_ids"])[0]
+    size = tuple(int(v) for v in o["image_size"])
+    keep = {}
+    vis = enc.encode_video(vid.cuda(), (vid + 0.01).cuda(), size, budget_text_len=len(ids), n_text_tokens=len(ids) - 1,
+                           prompt_ids=[int(i) for i in o["prompt_ids"]], keep=keep)
+    assert keep["seg_indices"] == o["out_seg_indices"].tolist()
+    emb = embed_fn(o)
+    pos = int(torch.where(ids == -200)[0][0])
+    full = torch.cat([emb(ids[:pos]), vis.float().cpu(), emb(ids[pos + 1:])])
+    ref = torch.from_numpy(o["out_inputs_embeds"])[0]
+    assert full.shape == ref.shape
+    assert rel(full, ref) < stage_tol(dtype)
+    if "nostatic" in name:
+        assert all(e[0] != "f" for e in keep["plan"]["src"]) and len(keep["plan"]["comp_frames"]) == 40
+
+
 @pytest.mark.parametrize("name", ["pipeline_T40.npz", "pipeline_T10_land.npz"])
 def test_mixin_boundary_vs_golden(name):
     """The drop-in boundary itself: CambrianMetaForCausalLM.prepare_inputs_labels_for_multimodal -> reference 10-tuple."""

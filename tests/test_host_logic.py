@@ -60,6 +60,24 @@ def test_unpad_geometry_and_masks(size):
         assert src[w] == (1, 0) and src[0] == (0, 3 * side * side + r0 * side + c0)
 
 
+def test_emit_plan_without_static_frames():
+    """add_static=False: every frame (key frames and single-frame chunks included) is compressed, K+1 tokens each."""
+    T, N, K = 21, 7, 3
+    segi = [2, 3, 9]                                         # chunks: [0,3) [3,4) [4,10) [10,18) [18,21)
+    plan = seg.emit_plan(T, N, K, segi, 10 ** 9, add_static=False)
+    assert plan["chunks"] == [(0, 3), (3, 4), (4, 10), (10, 18), (18, 21)]
+    assert plan["comp_frames"] == list(range(T))
+    assert plan["key_frames"] == [0, 3, 4, 10, 18]
+    assert plan["comp_chunk"] == [0] * 3 + [1] + [2] * 6 + [3] * 8 + [4] * 3
+    assert all(e[0] != "f" for e in plan["src"]) and len(plan["src"]) == T * (K + 1)
+    assert plan["src"][:K + 1] == [("c", 0, 0), ("c", 0, 1), ("c", 0, 2), ("s",)]
+    # tail clipping removes ceil(excess / n_chunks) tokens from the end of every chunk's block
+    clipped = seg.emit_plan(T, N, K, segi, T * (K + 1) - 7, add_static=False)
+    assert len(clipped["src"]) == T * (K + 1) - 2 * 5
+    # default unchanged
+    assert seg.emit_plan(T, N, K, segi, 10 ** 9) == seg.emit_plan(T, N, K, segi, 10 ** 9, add_static=True)
+
+
 def test_emit_plan_layout_and_clipping():
     T, N, K = 40, 20, 4
     segi = [1, 2, 4, 5, 7, 8, 11, 13, 14, 16, 17, 18, 19, 20, 22, 23, 24, 25, 26, 29, 32, 34, 35, 38]

@@ -108,6 +108,18 @@ def test_full_pipeline(name, stride):
     close(r["inputs_embeds"], o["out_inputs_embeds"])
 
 
+@pytest.mark.parametrize("name", ["pipeline_T40_nostatic.npz", "pipeline_T40_learned.npz"])
+def test_pipeline_config_ablations(name):
+    """add_static=False (every frame compressed, no static tokens) and query_type='learned' (query_tokens), generated
+    from the reference with those config values (tdc/cambrian_arch.py:1509-1511,1625-1640,1668-1692)."""
+    r, o = _run_pipeline(name)
+    assert np.array_equal(r["seg_indices"].numpy(), o["out_seg_indices"])
+    close(r["inputs_embeds"], o["out_inputs_embeds"])
+    if "nostatic" in name:
+        n_text = o["input_ids"].shape[1] - 1
+        assert r["inputs_embeds"].shape[1] == n_text + 40 * (4 + 1)
+
+
 def test_pipeline_token_accounting():
     """T=40 -> static frames emit N+1 tokens, compressed frames K+1."""
     r, o = _run_pipeline("pipeline_T40.npz")
