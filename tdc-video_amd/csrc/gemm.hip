@@ -17,6 +17,7 @@
 #include "../../include/tdc_hip.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -459,7 +460,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     };
 
     // ---- fragment read offsets inside a half
-    const int wm = wave >> 2, wn_ = wave & 3;
+    // wave -> (row, column) of the 2 x 4 wave grid: the two waves of a SIMD (w and w+4) take wave columns c and c+2, so
+    // in a tile whose upper half of the columns lies beyond N (N = 1152: the 5th column tile) every SIMD keeps exactly one
+    // working wave and the idle partner's MFMA slots are not wasted
+    const int wm = (wave >> 1) & 1, wn_ = (wave & 1) | ((wave >> 2) << 1);
+    const bool wave_active = n0 + wn_ * 64 < p.N;   // wave-uniform: this wave owns at least one valid column
     const int fr = lane & 15, g = lane >> 4;
     int a_off[4], w_off[2];
 #pragma unroll
@@ -489,7 +494,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     __builtin_amdgcn_s_barrier();                               \
     __builtin_amdgcn_sched_barrier(0)
 #define T2_LOAD_A(buf, h)                                                          \
-    {                                                                               \
+    if (active) {                                                                   \
         const char* base = smem + (buf) * T2_BUF + (h) * T2_HALF;                   \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                             \
             fa[i][0] = *(const v8*)(base + a_off[i]);                               \
@@ -497,7 +502,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         }                                                                           \
     }
 #define T2_LOAD_B(dst, buf, h)                                                      \
-    {                                                                               \
+    if (active) {                                                                   \
         const char* base = smem + (buf) * T2_BUF + (2 + (h)) * T2_HALF;             \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                             \
             dst[j][0] = *(const v8*)(base + w_off[j]);                              \
@@ -505,7 +510,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         }                                                                           \
     }
 #define T2_MMA(MI0, NJ0, fbx)                                                       \
-    {                                                                               \
+    if (active) {                                                                   \
         __builtin_amdgcn_s_setprio(1);                                              \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                            \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                               \
@@ -514,6 +519,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         __builtin_amdgcn_s_setprio(0);                                              \
     }
 
+    // The pipeline is instantiated twice: the working form, and a form for waves without a valid column that only stages
+    // and keeps the barriers (a run-time branch around the MFMA clusters inside ONE loop costs the working form ~5 %).
+    auto pipeline = [&](auto active_c) {
+    constexpr bool active = decltype(active_c)::value;
     // ---- prologue: tile 0 complete + tile 1's A0 B0 B1
     stage_a(0, 0, 0); stage_w(0, 0, 0); stage_w(0, 1, 0); stage_a(0, 1, 0);
     if (nk > 1) {
@@ -562,6 +571,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         T2_BARRIER();
     }
     if (wave < 4) T2_BARRIER();   // matches the stagger barrier of waves 4-7
+    };
+    if (wave_active) pipeline(std::true_type()); else pipeline(std::false_type());
 #undef T2_END_LOADS
 #undef T2_BARRIER
 #undef T2_LOAD_A
@@ -578,6 +589,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     }
     if (p.debug != 2) {
         T2_EPI_BARRIER();   // every wave is past its last LDS read: the pipeline buffers become staging space
+        if (!wave_active) return;
         if (epilogue_staged<T>(p, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn_ * 64, lane)) return;
     }
     epilogue<T, 8, 4>(p, acc, m0 + wm * 128, n0 + wn_ * 64, fr, g);
