@@ -282,7 +282,7 @@ __device__ __forceinline__ void epi_staged16(const GemmArgs& p, f32x4 (&acc)[8][
         const int r = q * 8 + (lane >> 3), k = lane & 7;
         const v8 val = *(const v8*)(region + r * 128 + ((k ^ (r & 7)) << 4));
         const int m = mbase + r, n = nbase + k * 8;
-        if (m < p.M && n < p.N) *(v8*)((T*)p.C + p.cm(m) * p.ldc + n) = val;
+        if (m < p.M && n < p.N) __builtin_nontemporal_store(val, (v8*)((T*)p.C + p.cm(m) * p.ldc + n));
     }
 }
 
@@ -321,7 +321,7 @@ __device__ __forceinline__ void epi_staged_swiglu(const GemmArgs& p, f32x4 (&acc
         const int r = q * 16 + (lane >> 2), k = lane & 3;
         const v8 val = *(const v8*)(region + r * 64 + ((k ^ ((r >> 2) & 3)) << 4));
         const int m = mbase + r, nc = (nbase >> 1) + k * 8;
-        if (m < p.M && 2 * nc < p.N) *(v8*)((T*)p.C + p.cm(m) * p.ldc + nc) = val;
+        if (m < p.M && 2 * nc < p.N) __builtin_nontemporal_store(val, (v8*)((T*)p.C + p.cm(m) * p.ldc + nc));
     }
 }
 
@@ -368,7 +368,7 @@ __device__ __forceinline__ void epi_staged32(const GemmArgs& p, f32x4 (&acc)[8][
                 f32x4 val = *(const f32x4*)(region + r * 256 + ((k ^ (r & 15)) << 4));
                 const int m = mbase + half * 64 + r, n = nbase + k * 4;
                 if (RES == 1) val += rr[q];
-                if (m < p.M && n < p.N) *(f32x4*)((float*)p.C + p.cm(m) * p.ldc + n) = val;
+                if (m < p.M && n < p.N) __builtin_nontemporal_store(val, (f32x4*)((float*)p.C + p.cm(m) * p.ldc + n));
             }
         }
     }

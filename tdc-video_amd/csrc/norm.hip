@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void ln_kernel(LnArgs p) {
         f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (c < p.cols) {
             if (p.x_f32) {
-                a = *(const f32x4*)((const float*)p.x + xrow * p.ldx + c);
+                a = __builtin_nontemporal_load((const f32x4*)((const float*)p.x + xrow * p.ldx + c));
             } else {
                 v4 h = *(const v4*)((const T*)p.x + xrow * p.ldx + c);
 #pragma unroll
