@@ -1,0 +1,57 @@
+"""Per tower-GEMM type (real epilogue: fp32 residual RMW / GELU / SwiGLU / plain 16-bit): time of the whole kernel vs the
+same launch with the epilogue skipped (TDC_GEMM_DEBUG=1), i.e. the share of the C-tile drain.  bf16, one MI355X."""
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tdc_video_amd  # noqa: F401,E402
+from tdc_video_amd import ops, lib as L  # noqa: E402
+from tools.bench_ops import timeit  # noqa: E402
+
+
+def main():
+    frames = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    dtype = torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(0)
+    Ms, Md = frames * 729, frames * 730
+    cases = [  # name, M, N, K, act, residual
+        ("siglip qkv", Ms, 3456, 1152, L.ACT_NONE, False),
+        ("siglip out", Ms, 1152, 1152, L.ACT_NONE, True),
+        ("siglip fc1", Ms, 4352, 1152, L.ACT_GELU_TANH, False),
+        ("siglip fc2", Ms, 1152, 4352, L.ACT_NONE, True),
+        ("dino qkv", Md, 4608, 1536, L.ACT_NONE, False),
+        ("dino out", Md, 1536, 1536, L.ACT_NONE, True),
+        ("dino fc1", Md, 8192, 1536, L.ACT_SWIGLU, False),
+        ("dino fc2", Md, 1536, 4096, L.ACT_NONE, True),
+    ]
+    tot = [0.0, 0.0]
+    for name, M, N, K, act, res in cases:
+        a = torch.randn(M, K, device="cuda", generator=g).to(dtype)
+        w = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).to(dtype)
+        bias = torch.randn(N, device="cuda", generator=g)
+        n_out = N // 2 if act == L.ACT_SWIGLU else N
+        if res:
+            x = torch.randn(M, N, device="cuda", generator=g)
+            fn = lambda: ops.gemm(a, w, bias=bias, res=x, out=x, out_f32=True)
+        else:
+            out = torch.empty(M, n_out, device="cuda", dtype=dtype)
+            fn = lambda: ops.gemm(a, w, bias=bias, act=act, out=out)
+        os.environ.pop("TDC_GEMM_DEBUG", None)
+        ms = timeit(fn, iters=10)
+        os.environ["TDC_GEMM_DEBUG"] = "1"
+        ms0 = timeit(fn, iters=10)
+        os.environ.pop("TDC_GEMM_DEBUG", None)
+        fl = 2.0 * M * N * K
+        layers = 27 if name.startswith("siglip") else 40
+        tot[0] += ms * layers; tot[1] += ms0 * layers
+        print("%-11s M=%6d N=%5d K=%5d  %7.3f ms %7.1f TF/s | no-epilogue %7.3f ms %7.1f TF/s | epilogue %4.1f %%"
+              % (name, M, N, K, ms, fl / ms / 1e9, ms0, fl / ms0 / 1e9, 100 * (ms - ms0) / ms), flush=True)
+        del a, w
+    print("towers (x layers): %.1f ms, without epilogues %.1f ms" % (tot[0], tot[1]))
+
+
+if __name__ == "__main__":
+    main()
