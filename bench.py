@@ -305,7 +305,7 @@ def main():
         kv_busy = max((r.get("mfma_busy_frac", 0) for r in summ["shapes"] if r["N"] >= 9216 and r["K"] == H), default=None)
     roofline = dict(bound="mfma", achieved=round(achieved, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(achieved / MFMA_PEAK_TFLOPS, 4), traffic=traffic,
-                    kernel="gemm256_kernel / gemm_kernel (tdc_gemm)",
+                    kernel="gemm256p_kernel / gemm256_kernel / gemm_kernel (tdc_gemm)",
                     launches=len(prof["gemm"]), avg_launch_us=round(g_ms * 1e3 / max(1, len(prof["gemm"])), 2),
                     gemm_ms_per_step=round(g_ms, 2), gemm_tflop_per_step=round(g_fl / 1e12, 2),
                     attention=dict(ms_per_step=round(a_ms, 2),

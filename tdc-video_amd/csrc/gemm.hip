@@ -32,13 +32,50 @@ struct GemmArgs {
     RowMap am, cm, rm;
     int tiles_m, tiles_n;
     int debug;   // TDC_GEMM_DEBUG: 1 = skip the epilogue, 2 = direct (un-staged) epilogue - timing experiments only
+#ifdef TDC_GEMM_DIAG
+    unsigned long long* stamps;   // diagnostics build only (tools/gemm_stamps.cpp): 8 x u64 per workgroup
+#endif
 };
+
+// In-kernel timeline stamps (s_memrealtime, 100 MHz) of wave 0 - compiled only into the diagnostics build
+#ifdef TDC_GEMM_DIAG
+#define TDC_STAMP(k)                                                                              \
+    if (p.stamps && threadIdx.x == 0) {                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        p.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime();               \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+    }
+#else
+#define TDC_STAMP(k)
+#endif
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     // bijective "contiguous chunk per XCD" remap (cdna_hip_programming.md T1): blocks b, b+8, ... share an XCD
     int q = nwg >> 3, r = nwg & 7, x = bid & 7;
     int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
     return base + (bid >> 3);
+}
+
+// Bias vectors of a wave's 64 columns in the MFMA layout (lane (fr, g) needs columns j*16 + 4g .. +3 of column tile j).
+// LANE = false: loaded from global memory here.  LANE = true (persistent kernel): lane L already holds bias[nbase + L]
+// in `bias_lane` (loaded one tile ahead, so that no vector-memory load - whose in-order vmcnt wait would also wait for
+// the next tile's staged operands - sits at the start of the epilogue); the vectors are gathered with ds_bpermute.
+template <bool LANE, int NJ>
+__device__ __forceinline__ void get_bias(const GemmArgs& p, int nbase, int lane, float bias_lane, f32x4 (&bias)[NJ]) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        if (LANE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                bias[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((j * 16 + g * 4 + e) * 4,
+                                                                                    __builtin_bit_cast(int, bias_lane)));
+        } else {
+            const int n = nbase + j * 16 + g * 4;
+            bias[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (p.bias && n < p.N) bias[j] = *(const f32x4*)(p.bias + n);
+        }
+    }
 }
 
 // ---- epilogue -------------------------------------------------------------------------------------------------------
@@ -87,16 +124,11 @@ __device__ __forceinline__ void epi_store(const GemmArgs& p, f32x4 v, f32x4 bias
     }
 }
 
-template <class T, int MI, int NJ, int ACT, int RES, bool OUTF32>
+template <class T, int MI, int NJ, int ACT, int RES, bool OUTF32, bool LB>
 __device__ __forceinline__ void epi_tile(const GemmArgs& p, f32x4 (&acc)[MI][NJ], int mbase, int nbase, int fr,
-                                         int g) {
+                                         int g, float bias_lane) {
     f32x4 bias[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int n = nbase + j * 16 + g * 4;
-        bias[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (p.bias && n < p.N) bias[j] = *(const f32x4*)(p.bias + n);
-    }
+    get_bias<LB, NJ>(p, nbase, fr + g * 16, bias_lane, bias);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = mbase + i * 16 + fr;
@@ -112,20 +144,21 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& p, f32x4 (&acc)[MI][NJ]
     }
 }
 
-template <class T, int MI, int NJ>
-__device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[MI][NJ], int mbase, int nbase, int fr, int g) {
+template <class T, int MI, int NJ, bool LB = false>
+__device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[MI][NJ], int mbase, int nbase, int fr, int g,
+                                         float bias_lane = 0.f) {
     const int res = p.res ? (p.res_f32 ? 1 : 2) : 0;
-    if (p.act == TDC_ACT_GELU_ERF) epi_tile<T, MI, NJ, TDC_ACT_GELU_ERF, 0, false>(p, acc, mbase, nbase, fr, g);
-    else if (p.act == TDC_ACT_GELU_TANH) epi_tile<T, MI, NJ, TDC_ACT_GELU_TANH, 0, false>(p, acc, mbase, nbase, fr, g);
-    else if (p.act == TDC_ACT_SWIGLU) epi_tile<T, MI, NJ, TDC_ACT_SWIGLU, 0, false>(p, acc, mbase, nbase, fr, g);
+    if (p.act == TDC_ACT_GELU_ERF) epi_tile<T, MI, NJ, TDC_ACT_GELU_ERF, 0, false, LB>(p, acc, mbase, nbase, fr, g, bias_lane);
+    else if (p.act == TDC_ACT_GELU_TANH) epi_tile<T, MI, NJ, TDC_ACT_GELU_TANH, 0, false, LB>(p, acc, mbase, nbase, fr, g, bias_lane);
+    else if (p.act == TDC_ACT_SWIGLU) epi_tile<T, MI, NJ, TDC_ACT_SWIGLU, 0, false, LB>(p, acc, mbase, nbase, fr, g, bias_lane);
     else if (p.out_f32) {
-        if (res == 1) epi_tile<T, MI, NJ, 0, 1, true>(p, acc, mbase, nbase, fr, g);
-        else if (res == 2) epi_tile<T, MI, NJ, 0, 2, true>(p, acc, mbase, nbase, fr, g);
-        else epi_tile<T, MI, NJ, 0, 0, true>(p, acc, mbase, nbase, fr, g);
+        if (res == 1) epi_tile<T, MI, NJ, 0, 1, true, LB>(p, acc, mbase, nbase, fr, g, bias_lane);
+        else if (res == 2) epi_tile<T, MI, NJ, 0, 2, true, LB>(p, acc, mbase, nbase, fr, g, bias_lane);
+        else epi_tile<T, MI, NJ, 0, 0, true, LB>(p, acc, mbase, nbase, fr, g, bias_lane);
     } else {
-        if (res == 1) epi_tile<T, MI, NJ, 0, 1, false>(p, acc, mbase, nbase, fr, g);
-        else if (res == 2) epi_tile<T, MI, NJ, 0, 2, false>(p, acc, mbase, nbase, fr, g);
-        else epi_tile<T, MI, NJ, 0, 0, false>(p, acc, mbase, nbase, fr, g);
+        if (res == 1) epi_tile<T, MI, NJ, 0, 1, false, LB>(p, acc, mbase, nbase, fr, g, bias_lane);
+        else if (res == 2) epi_tile<T, MI, NJ, 0, 2, false, LB>(p, acc, mbase, nbase, fr, g, bias_lane);
+        else epi_tile<T, MI, NJ, 0, 0, false, LB>(p, acc, mbase, nbase, fr, g, bias_lane);
     }
 }
 
@@ -232,170 +265,172 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 // and stores whole rows: one instruction = 8 rows x 128 B (16-bit out) or 4 rows x 256 B (fp32 out), 16 B per lane.
 // Bias / activation run before staging (MFMA layout, one bias vector per column tile); the fp32 residual add runs
 // after it, on full 256-B row segments.  XOR swizzle of the 16-B chunk with the row keeps both sides (nearly) conflict-free.
-template <class T, int ACT, int RES>
+template <class T, int ACT, int RES, int ROWS, bool LB>
 __device__ __forceinline__ void epi_staged16(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase, int nbase,
-                                             int lane) {
+                                             int lane, float bias_lane) {
+    // ROWS = rows of the wave's 128x64 sub-tile staged per pass (128-byte rows): 128 (16 KiB region) or 32 (4 KiB)
     typedef typename VecOf<T>::v4 v4;
     typedef typename VecOf<T>::v8 v8;
     const int fr = lane & 15, g = lane >> 4;
     f32x4 bias[4];
+    get_bias<LB, 4>(p, nbase, lane, bias_lane, bias);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = nbase + j * 16 + g * 4;
-        bias[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (p.bias && n < p.N) bias[j] = *(const f32x4*)(p.bias + n);
-    }
+    for (int pass = 0; pass < 128 / ROWS; ++pass) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int r = i * 16 + fr;
-        const int m = mbase + r;
-        long long rrow = 0;
-        if (RES == 2) rrow = p.rm(m < p.M ? m : p.M - 1);
+        for (int ii = 0; ii < ROWS / 16; ++ii) {
+            const int i = pass * (ROWS / 16) + ii;
+            const int r = ii * 16 + fr;                 // row within the staging region
+            const int m = mbase + i * 16 + fr;
+            long long rrow = 0;
+            if (RES == 2) rrow = p.rm(m < p.M ? m : p.M - 1);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x4 v = acc[i][j] + bias[j];
-            if (ACT == TDC_ACT_GELU_ERF) {
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v = acc[i][j] + bias[j];
+                if (ACT == TDC_ACT_GELU_ERF) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-            } else if (ACT == TDC_ACT_GELU_TANH) {
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                } else if (ACT == TDC_ACT_GELU_TANH) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
-            }
-            if (RES == 2) {   // 16-bit residual: add before the single rounding to T
-                const int n = nbase + j * 16 + g * 4;
-                if (n < p.N) {
-                    v4 rr = *(const v4*)((const T*)p.res + rrow * p.ldres + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
                 }
+                if (RES == 2) {   // 16-bit residual: add before the single rounding to T
+                    const int n = nbase + j * 16 + g * 4;
+                    if (n < p.N) {
+                        v4 rr = *(const v4*)((const T*)p.res + rrow * p.ldres + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+                    }
+                }
+                v4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (T)v[e];
+                const int chunk = (j * 2 + (g >> 1)) ^ (r & 7);
+                *(v4*)(region + r * 128 + chunk * 16 + (g & 1) * 8) = o;
             }
-            v4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (T)v[e];
-            const int chunk = (j * 2 + (g >> 1)) ^ (r & 7);
-            *(v4*)(region + r * 128 + chunk * 16 + (g & 1) * 8) = o;
         }
-    }
-    // same wave, in-order LDS queue: the reads below observe the writes above
+        // same wave, in-order LDS queue: the reads below observe the writes above (and the next pass's writes follow
+        // these reads)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int r = q * 8 + (lane >> 3), k = lane & 7;
-        const v8 val = *(const v8*)(region + r * 128 + ((k ^ (r & 7)) << 4));
-        const int m = mbase + r, n = nbase + k * 8;
-        if (m < p.M && n < p.N) __builtin_nontemporal_store(val, (v8*)((T*)p.C + p.cm(m) * p.ldc + n));
+        for (int q = 0; q < ROWS / 8; ++q) {
+            const int r = q * 8 + (lane >> 3), k = lane & 7;
+            const v8 val = *(const v8*)(region + r * 128 + ((k ^ (r & 7)) << 4));
+            const int m = mbase + pass * ROWS + r, n = nbase + k * 8;
+            if (m < p.M && n < p.N) __builtin_nontemporal_store(val, (v8*)((T*)p.C + p.cm(m) * p.ldc + n));
+        }
     }
 }
 
 // SwiGLU: columns are interleaved (x1_j, x2_j); each lane produces 2 outputs per accumulator tile, the wave's 128x64
 // sub-tile becomes 128 rows x 32 outputs (64-byte rows, 8 KiB).  Staging turns 32 four-byte stores per lane (16 rows
 // x 16 B per instruction) into 8 sixteen-byte stores (16 rows x 64 B per instruction).
-template <class T>
+template <class T, int ROWS, bool LB>
 __device__ __forceinline__ void epi_staged_swiglu(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase,
-                                                  int nbase, int lane) {
+                                                  int nbase, int lane, float bias_lane) {
     typedef __attribute__((ext_vector_type(2))) T v2;
     typedef typename VecOf<T>::v8 v8;
     const int fr = lane & 15, g = lane >> 4;
     f32x4 bias[4];
+    get_bias<LB, 4>(p, nbase, lane, bias_lane, bias);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = nbase + j * 16 + g * 4;
-        bias[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (p.bias && n < p.N) bias[j] = *(const f32x4*)(p.bias + n);
-    }
+    for (int pass = 0; pass < 128 / ROWS; ++pass) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int r = i * 16 + fr;
+        for (int ii = 0; ii < ROWS / 16; ++ii) {
+            const int i = pass * (ROWS / 16) + ii;
+            const int r = ii * 16 + fr;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 v = acc[i][j] + bias[j];
-            v2 o;
-            o[0] = (T)(silu(v[0]) * v[1]);
-            o[1] = (T)(silu(v[2]) * v[3]);
-            // output column within the wave's 32: j*8 + 2g -> 16-B chunk j (4 per row), swizzled with the row
-            const int chunk = j ^ ((r >> 2) & 3);
-            *(v2*)(region + r * 64 + chunk * 16 + g * 4) = o;
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 v = acc[i][j] + bias[j];
+                v2 o;
+                o[0] = (T)(silu(v[0]) * v[1]);
+                o[1] = (T)(silu(v[2]) * v[3]);
+                // output column within the wave's 32: j*8 + 2g -> 16-B chunk j (4 per row), swizzled with the row
+                const int chunk = j ^ ((r >> 2) & 3);
+                *(v2*)(region + r * 64 + chunk * 16 + g * 4) = o;
+            }
         }
-    }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int r = q * 16 + (lane >> 2), k = lane & 3;
-        const v8 val = *(const v8*)(region + r * 64 + ((k ^ ((r >> 2) & 3)) << 4));
-        const int m = mbase + r, nc = (nbase >> 1) + k * 8;
-        if (m < p.M && 2 * nc < p.N) __builtin_nontemporal_store(val, (v8*)((T*)p.C + p.cm(m) * p.ldc + nc));
+        for (int q = 0; q < ROWS / 16; ++q) {
+            const int r = q * 16 + (lane >> 2), k = lane & 3;
+            const v8 val = *(const v8*)(region + r * 64 + ((k ^ ((r >> 2) & 3)) << 4));
+            const int m = mbase + pass * ROWS + r, nc = (nbase >> 1) + k * 8;
+            if (m < p.M && 2 * nc < p.N) __builtin_nontemporal_store(val, (v8*)((T*)p.C + p.cm(m) * p.ldc + nc));
+        }
     }
 }
 
-template <class T, int RES>
+template <class T, int RES, int ROWS, bool LB>
 __device__ __forceinline__ void epi_staged32(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase, int nbase,
-                                             int lane) {
+                                             int lane, float bias_lane) {
+    // ROWS = rows staged per pass (256-byte fp32 rows): 64 (16 KiB region) or 16 (4 KiB)
     const int fr = lane & 15, g = lane >> 4;
     f32x4 bias[4];
+    get_bias<LB, 4>(p, nbase, lane, bias_lane, bias);
+    constexpr int NPASS = 128 / ROWS, QP = ROWS / 4;      // QP read-back instructions (4 rows x 256 B each) per pass
+    // The residual loads run as a ring of RING loads ahead of the read-back, independent of the staging passes (they
+    // touch no LDS); they come from clamped (always valid) addresses so that no branch - and no vmcnt(0) - separates them.
+    constexpr int RING = 8;
+    f32x4 rr[RING];
+    auto load_res = [&](int u) {                           // unit u = rows 4u .. 4u+3 of the wave's sub-tile
+        const int k = lane & 15;
+        int m = mbase + u * 4 + (lane >> 4), n = nbase + k * 4;
+        if (m > p.M - 1) m = p.M - 1;
+        if (n > p.N - 4) n = p.N - 4;
+        return *(const f32x4*)((const float*)p.res + p.rm(m) * p.ldres + n);
+    };
+    if (RES == 1) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = nbase + j * 16 + g * 4;
-        bias[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (p.bias && n < p.N) bias[j] = *(const f32x4*)(p.bias + n);
+        for (int u = 0; u < RING; ++u) rr[u] = load_res(u);
     }
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {       // 64 rows x 64 fp32 = 16 KiB per pass
+    for (int pass = 0; pass < NPASS; ++pass) {
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
+        for (int ii = 0; ii < ROWS / 16; ++ii) {
             const int r = ii * 16 + fr;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int chunk = (j * 4 + g) ^ (r & 15);
-                *(f32x4*)(region + r * 256 + chunk * 16) = acc[half * 4 + ii][j] + bias[j];
+                *(f32x4*)(region + r * 256 + chunk * 16) = acc[pass * (ROWS / 16) + ii][j] + bias[j];
             }
         }
-        // read back 4 rows x 256 B per instruction; the residual loads of a batch are issued back to back from clamped
-        // (always valid) addresses so that no branch - and no vmcnt(0) - separates them
 #pragma unroll
-        for (int qb = 0; qb < 16; qb += 8) {
-            f32x4 rr[8];
+        for (int q = 0; q < QP; ++q) {
+            const int u = pass * QP + q;
+            const int r = q * 4 + (lane >> 4), k = lane & 15;
+            f32x4 val = *(const f32x4*)(region + r * 256 + ((k ^ (r & 15)) << 4));
+            const int m = mbase + pass * ROWS + r, n = nbase + k * 4;
             if (RES == 1) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int r = (qb + q) * 4 + (lane >> 4), k = lane & 15;
-                    int m = mbase + half * 64 + r, n = nbase + k * 4;
-                    if (m > p.M - 1) m = p.M - 1;
-                    if (n > p.N - 4) n = p.N - 4;
-                    rr[q] = *(const f32x4*)((const float*)p.res + p.rm(m) * p.ldres + n);
-                }
+                val += rr[u % RING];
+                if (u + RING < 32) rr[u % RING] = load_res(u + RING);
             }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int r = (qb + q) * 4 + (lane >> 4), k = lane & 15;
-                f32x4 val = *(const f32x4*)(region + r * 256 + ((k ^ (r & 15)) << 4));
-                const int m = mbase + half * 64 + r, n = nbase + k * 4;
-                if (RES == 1) val += rr[q];
-                if (m < p.M && n < p.N) __builtin_nontemporal_store(val, (f32x4*)((float*)p.C + p.cm(m) * p.ldc + n));
-            }
+            if (m < p.M && n < p.N) __builtin_nontemporal_store(val, (f32x4*)((float*)p.C + p.cm(m) * p.ldc + n));
         }
     }
 }
 
-// returns false when this (act, res, out) combination / alignment has no staged variant
-template <class T>
+// returns false when this (act, res, out) combination / alignment has no staged variant.  SMALL: 4 KiB staging region
+// per wave (the persistent kernel stages beside the live pipeline buffers), otherwise 16 KiB (the idle pipeline LDS).
+template <class T, bool SMALL>
 __device__ __forceinline__ bool epilogue_staged(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase,
-                                                int nbase, int lane) {
+                                                int nbase, int lane, float bias_lane = 0.f) {
     const int res = p.res ? (p.res_f32 ? 1 : 2) : 0;
+    constexpr int R16 = SMALL ? 32 : 128, RSW = SMALL ? 64 : 128, R32 = SMALL ? 16 : 64;
     if (p.out_f32) {
         if (p.act != TDC_ACT_NONE || res == 2) return false;
-        if (res == 1) epi_staged32<T, 1>(p, acc, region, mbase, nbase, lane);
-        else epi_staged32<T, 0>(p, acc, region, mbase, nbase, lane);
+        if (res == 1) epi_staged32<T, 1, R32, SMALL>(p, acc, region, mbase, nbase, lane, bias_lane);
+        else epi_staged32<T, 0, R32, SMALL>(p, acc, region, mbase, nbase, lane, bias_lane);
         return true;
     }
     if (res == 1 || (p.ldc & 7) || ((uintptr_t)p.C & 15)) return false;
     if (p.act == TDC_ACT_SWIGLU) {
         if (p.N & 15) return false;
-        epi_staged_swiglu<T>(p, acc, region, mbase, nbase, lane);
+        epi_staged_swiglu<T, RSW, SMALL>(p, acc, region, mbase, nbase, lane, bias_lane);
         return true;
     }
     if (p.N & 7) return false;
-    if (p.act == TDC_ACT_GELU_ERF) epi_staged16<T, TDC_ACT_GELU_ERF, 0>(p, acc, region, mbase, nbase, lane);
-    else if (p.act == TDC_ACT_GELU_TANH) epi_staged16<T, TDC_ACT_GELU_TANH, 0>(p, acc, region, mbase, nbase, lane);
-    else if (res == 2) epi_staged16<T, 0, 2>(p, acc, region, mbase, nbase, lane);
-    else epi_staged16<T, 0, 0>(p, acc, region, mbase, nbase, lane);
+    if (p.act == TDC_ACT_GELU_ERF) epi_staged16<T, TDC_ACT_GELU_ERF, 0, R16, SMALL>(p, acc, region, mbase, nbase, lane, bias_lane);
+    else if (p.act == TDC_ACT_GELU_TANH) epi_staged16<T, TDC_ACT_GELU_TANH, 0, R16, SMALL>(p, acc, region, mbase, nbase, lane, bias_lane);
+    else if (res == 2) epi_staged16<T, 0, 2, R16, SMALL>(p, acc, region, mbase, nbase, lane, bias_lane);
+    else epi_staged16<T, 0, 0, R16, SMALL>(p, acc, region, mbase, nbase, lane, bias_lane);
     return true;
 }
 
@@ -427,6 +462,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     int tm, tn;
     tile_coords(id, p.tiles_m, p.tiles_n, tm, tn);
     const int m0 = tm * 256, n0 = tn * 256;
+#ifdef TDC_GEMM_DIAG
+    if (p.stamps && threadIdx.x == 0) {
+        p.stamps[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_ID
+        p.stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg((3 << 11) | 20);     // XCC_ID
+    }
+#endif
+    TDC_STAMP(0);
 
     // ---- staging sources: per half 2 glds per thread; instruction (wave*2 + j) covers half rows 8*(wave*2+j) .. +7
     const int srow = lane >> 3;
@@ -532,6 +574,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     T2_BARRIER();
+    TDC_STAMP(1);
     // stagger: waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in its MFMA cluster while its
     // partner is in its LDS-read / staging segment (MI355X_MICROARCH.md "Two waves per SIMD")
     if (wave >= 4) T2_BARRIER();
@@ -573,13 +616,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     if (wave < 4) T2_BARRIER();   // matches the stagger barrier of waves 4-7
     };
     if (wave_active) pipeline(std::true_type()); else pipeline(std::false_type());
-#undef T2_END_LOADS
-#undef T2_BARRIER
-#undef T2_LOAD_A
-#undef T2_LOAD_B
-#undef T2_MMA
 
     // ---- epilogue: lane holds C[m = m0 + wm*128 + 16 i + fr][n = n0 + wn*64 + 16 j + 4g .. +3]
+    TDC_STAMP(2);
     if (p.debug == 1) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -590,9 +629,270 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     if (p.debug != 2) {
         T2_EPI_BARRIER();   // every wave is past its last LDS read: the pipeline buffers become staging space
         if (!wave_active) return;
-        if (epilogue_staged<T>(p, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn_ * 64, lane)) return;
+        if (epilogue_staged<T, false>(p, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn_ * 64, lane)) {
+#ifdef TDC_GEMM_DIAG
+            TDC_STAMP(3);
+            if (p.debug == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            TDC_STAMP(4);
+#endif
+            return;
+        }
     }
     epilogue<T, 8, 4>(p, acc, m0 + wm * 128, n0 + wn_ * 64, fr, g);
+}
+
+// ======================================================================================================================
+// Persistent form of the 256^2 kernel: one workgroup per CU walks its tiles (static round-robin inside the XCD's contiguous
+// chunk of the grouped tile order, so the 32 workgroups of an XCD still cover the same patch of tiles at any time).
+// In-kernel stamps of the one-tile-per-workgroup kernel (tools/gemm_stamps.cpp) showed ~3 us per tile - 7 % of a K=1152
+// tile - between the last store of one workgroup and the first MFMA of the next (dispatch + first loads from HBM), and
+// that the C-tile drain itself is store-issue bound (~73 cycles per 1-KiB store instruction and CU), not latency bound.
+// Here the staging stream simply runs on across the tile seam: the last two K iterations of a tile stage K tiles 0 and 1
+// of the NEXT tile (the staging cursor switches its base pointers between phase 1 and phase 2 of iteration nk-2), the
+// epilogue stages through 4 KiB per wave BESIDE the 128 KiB pipeline buffers, and the next main loop starts with its
+// operands already in LDS.  Staging addresses are an SGPR tile base + 32-bit per-lane offsets (a_map must be identity).
+constexpr int T2P_LDS = T2_LDS + 8 * 4096;    // 160 KiB
+
+template <class T>
+__global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
+    typedef typename VecOf<T>::v8 v8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwg = p.tiles_m * p.tiles_n;
+    // ---- this workgroup's tiles: ids base + l + G8 * j of XCD x's chunk [base, base + len) (same chunks as xcd_remap)
+    const int G8 = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
+    const int cq = nwg >> 3, cr = nwg & 7;
+    const int chunk_base = (xcd < cr) ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
+    const int chunk_len = cq + (xcd < cr ? 1 : 0);
+    const int n_my = l < chunk_len ? (chunk_len - l + G8 - 1) / G8 : 0;
+    if (n_my == 0) return;
+
+    // ---- staging cursor: SGPR bases + per-lane byte offsets of the tile being staged
+    const int srow = lane >> 3;
+    const int schunk = (lane & 7) ^ srow;
+    unsigned a_so[2][2], w_so[2][2];
+    const char* a_base;
+    const char* w_base;
+    auto set_stage_tile = [&](int m0, int n0) {
+        a_base = (const char*)p.A + (long long)m0 * p.lda * 2;
+        w_base = (const char*)p.W + (long long)n0 * p.ldw * 2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = (wave * 2 + j) * 8 + srow;                       // row within the half (0..127)
+                int am = (r >> 6) * 128 + h * 64 + (r & 63);
+                int wn = (r >> 5) * 64 + h * 32 + (r & 31);
+                if (am > p.M - 1 - m0) am = p.M - 1 - m0;
+                if (wn > p.N - 1 - n0) wn = p.N - 1 - n0;
+                a_so[h][j] = (unsigned)(am * p.lda + schunk * 8) * 2u;
+                w_so[h][j] = (unsigned)(wn * p.ldw + schunk * 8) * 2u;
+            }
+    };
+    const int lds_stage = wave * 2 * 1024;
+    // one half-tile (2 x 1 KiB per wave) from the SGPR source `src` (tile base + K offset) + the per-lane offsets
+    auto stage_a = [&](int buf, int h, const char* src) {
+        char* dst = smem + buf * T2_BUF + h * T2_HALF + lds_stage;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src + a_so[h][0]), LDS_PTR(dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src + a_so[h][1]), LDS_PTR(dst + 1024), 16, 0, 0);
+    };
+    auto stage_w = [&](int buf, int h, const char* src) {
+        char* dst = smem + buf * T2_BUF + (2 + h) * T2_HALF + lds_stage;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src + w_so[h][0]), LDS_PTR(dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src + w_so[h][1]), LDS_PTR(dst + 1024), 16, 0, 0);
+    };
+
+    const int wm = (wave >> 1) & 1, wn_ = (wave & 1) | ((wave >> 2) << 1);
+    const int fr = lane & 15, g = lane >> 4;
+    int a_off[4], w_off[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = wm * 64 + i * 16 + fr;
+        a_off[i] = r * 128 + ((g ^ (r & 7)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = wn_ * 32 + j * 16 + fr;
+        w_off[j] = r * 128 + ((g ^ (r & 7)) << 4);
+    }
+
+    f32x4 acc[8][4];
+    v8 fa[4][2], fb0[2][2], fb1[2][2];
+    const int nk = p.K / 64;        // >= 2 (host)
+    int par = 0;                    // LDS buffer of the current tile's K tile 0
+
+    // running staging sources (SGPR pairs): pa1 = A source of the A1 half staged in phase 1 (K tile kt+1), pa2 / pw2 =
+    // A / W source of K tile kt+2.  They advance by one K tile (128 B) per iteration behind the last MFMA cluster and are
+    // re-based at the tile seam, so no address arithmetic sits in a load segment (the LDS-read -> barrier -> MFMA path).
+    const char *pa1, *pa2, *pw2;
+    // main loop of ONE tile; MORE = another tile follows (its first two K tiles are staged by the last two iterations),
+    // (m1, n1) = that tile's origin
+    auto tile_loop = [&](auto active_c, auto more_c, int m1, int n1) {
+        constexpr bool active = decltype(active_c)::value;
+        constexpr bool MORE = decltype(more_c)::value;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = (kt + par) & 1, nxt = cur ^ 1;
+            const bool s1 = kt + 1 < nk, s2 = kt + 2 < nk;
+            // ---- phase 1: quadrant (a0, b0)
+            T2_LOAD_B(fb0, cur, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            T2_LOAD_A(cur, 0);
+            __builtin_amdgcn_sched_barrier(0);      // LDS reads first: an LDS-DMA issue ahead of them delays the barrier
+            if (MORE || s1) stage_a(nxt, 1, pa1);
+            T2_END_LOADS();
+            T2_MMA(0, 0, fb0);
+            T2_BARRIER();
+            // the staging cursor crosses the tile seam here: everything staged from now on belongs to the next tile
+            if (MORE && kt == nk - 2) {
+                set_stage_tile(m1, n1);
+                pa2 = a_base; pw2 = w_base;
+            }
+            // ---- phase 2: quadrant (a0, b1)
+            T2_LOAD_B(fb1, cur, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (MORE || s2) stage_a(cur, 0, pa2);
+            T2_END_LOADS();
+            T2_MMA(0, 2, fb1);
+            T2_BARRIER();
+            // ---- phase 3: quadrant (a1, b1)
+            T2_LOAD_A(cur, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (MORE || s2) stage_w(cur, 0, pw2);
+            T2_END_LOADS();
+            T2_MMA(4, 2, fb1);
+            T2_BARRIER();
+            // ---- phase 4: quadrant (a1, b0); retire K tile kt+1 (3 half-tiles of kt+2 may stay in flight)
+            if (MORE || s2) {
+                stage_w(cur, 1, pw2);
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            T2_BARRIER();
+            __builtin_amdgcn_sched_barrier(0);
+            T2_MMA(4, 0, fb0);
+            pa1 = pa2; pa2 += 128; pw2 += 128;
+            __builtin_amdgcn_sched_barrier(0);
+            T2_BARRIER();
+        }
+    };
+
+    int id = chunk_base + l;
+    int tm, tn;
+    tile_coords(id, p.tiles_m, p.tiles_n, tm, tn);
+    int m0 = tm * 256, n0 = tn * 256;
+    // lane L keeps bias[n0 + wn*64 + L] of the tile being computed (see get_bias); the first one is waited for here,
+    // compiler-visibly, before any staging load is in flight
+    auto load_bias_lane = [&](int n0_) {
+        int n = n0_ + wn_ * 64 + lane;
+        if (n > p.N - 1) n = p.N - 1;
+        return p.bias ? p.bias[n] : 0.f;
+    };
+    float bias_lane = load_bias_lane(n0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    // ---- prologue of the first tile: K tile 0 complete + K tile 1's A0 B0 B1
+    set_stage_tile(m0, n0);
+    stage_a(0, 0, a_base); stage_w(0, 0, w_base); stage_w(0, 1, w_base); stage_a(0, 1, a_base);
+    stage_a(1, 0, a_base + 128); stage_w(1, 0, w_base + 128); stage_w(1, 1, w_base + 128);
+    pa1 = a_base + 128; pa2 = a_base + 256; pw2 = w_base + 256;
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    T2_BARRIER();
+    if (wave >= 4) T2_BARRIER();      // stagger (see gemm256_kernel)
+
+    for (int it = 0; it < n_my; ++it) {
+        const bool more = it + 1 < n_my;
+        int m1 = 0, n1 = 0;
+        if (more) {
+            int tm1, tn1;
+            tile_coords(id + G8, p.tiles_m, p.tiles_n, tm1, tn1);
+            m1 = tm1 * 256; n1 = tn1 * 256;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const bool wave_active = n0 + wn_ * 64 < p.N;
+#ifdef TDC_GEMM_DIAG
+        if (p.stamps && threadIdx.x == 0) {
+            p.stamps[(size_t)id * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+            p.stamps[(size_t)id * 8 + 6] = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+            __builtin_amdgcn_sched_barrier(0);
+            p.stamps[(size_t)id * 8 + 0] = p.stamps[(size_t)id * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
+        if (more) {
+            if (wave_active) tile_loop(std::true_type(), std::true_type(), m1, n1);
+            else tile_loop(std::false_type(), std::true_type(), m1, n1);
+        } else {
+            if (wave_active) tile_loop(std::true_type(), std::false_type(), m1, n1);
+            else tile_loop(std::false_type(), std::false_type(), m1, n1);
+        }
+        par ^= nk & 1;
+#ifdef TDC_GEMM_DIAG
+        if (p.stamps && threadIdx.x == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            p.stamps[(size_t)id * 8 + 2] = __builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
+        // ---- epilogue (no barrier: every wave stages through its own 4 KiB beside the pipeline buffers).  The lane id is
+        // made opaque per tile so that the epilogue's lane-derived addresses are recomputed here instead of being hoisted
+        // out of the tile loop, kept live across the main loop and spilled (their scratch reloads would sit behind the
+        // next tile's staged loads in the in-order vmcnt queue).
+        int elane = lane;
+        asm volatile("" : "+v"(elane));
+        const float next_bias_lane = more ? load_bias_lane(n1) : 0.f;    // complete by the vmcnt(0) below
+        if (wave_active && p.debug != 1) {
+            if (!epilogue_staged<T, true>(p, acc, smem + T2_LDS + wave * 4096, m0 + wm * 128, n0 + wn_ * 64, elane,
+                                          bias_lane))
+                epilogue<T, 8, 4, true>(p, acc, m0 + wm * 128, n0 + wn_ * 64, elane & 15, elane >> 4, bias_lane);
+        } else if (p.debug == 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+        }
+#ifdef TDC_GEMM_DIAG
+        if (p.stamps && threadIdx.x == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            p.stamps[(size_t)id * 8 + 3] = p.stamps[(size_t)id * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
+        // A compiler-visible vmcnt(0): without it the waitcnt pass protects the fragment registers of the next main loop
+        // against this epilogue's (long finished) loads with a vmcnt(0) INSIDE the K loop, which would drain the staging
+        // pipeline every iteration.  Here it only waits for the acknowledgement of the last stores.  Unconditional: the
+        // pass cannot tell that !more leaves the loop.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        bias_lane = next_bias_lane;
+        id += G8; m0 = m1; n0 = n1;
+    }
+    if (wave < 4) T2_BARRIER();   // matches the stagger barrier of waves 4-7
+}
+#undef T2_END_LOADS
+#undef T2_BARRIER
+#undef T2_LOAD_A
+#undef T2_LOAD_B
+#undef T2_MMA
+
+// workgroups of the persistent kernel = CUs of the device rounded down to a multiple of 8 (one per CU: 160 KiB of LDS);
+// 0 disables it (TDC_GEMM_PERSIST=0, or a device whose LDS cannot hold 160 KiB per workgroup)
+inline int persistent_grid() {
+    static int grid = -1;
+    if (grid < 0) {
+        const char* e = getenv("TDC_GEMM_PERSIST");
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if ((e && atoi(e) == 0) || hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+            prop.sharedMemPerBlock < (size_t)T2P_LDS)
+            grid = 0;
+        else
+            grid = (prop.multiProcessorCount / 8) * 8;
+    }
+    return grid;
 }
 
 // kernel choice: the 256^2 8-phase kernel needs enough tiles to fill the 256 CUs; TDC_GEMM_FORCE=128|256 overrides
@@ -608,6 +908,11 @@ inline bool use_256(int M, int N, int K) {
     return t256 >= 192 && K >= 128;
 }
 
+#ifdef TDC_GEMM_DIAG
+}
+unsigned long long* tdc_gemm_diag_stamps = nullptr;   // set by tools/gemm_stamps.cpp
+namespace {
+#endif
 template <class T>
 int launch(const tdc_gemm_desc* d, hipStream_t st) {
     GemmArgs a;
@@ -616,6 +921,9 @@ int launch(const tdc_gemm_desc* d, hipStream_t st) {
     a.M = d->M; a.N = d->N; a.K = d->K;
     a.out_f32 = d->out_f32; a.res_f32 = d->res_f32; a.act = d->act;
     { const char* e = getenv("TDC_GEMM_DEBUG"); a.debug = e ? atoi(e) : 0; }
+#ifdef TDC_GEMM_DIAG
+    a.stamps = tdc_gemm_diag_stamps;
+#endif
     a.am = {d->a_map.seg, d->a_map.stride, d->a_map.off, d->a_map.inner};
     a.cm = {d->c_map.seg, d->c_map.stride, d->c_map.off, d->c_map.inner};
     a.rm = {d->r_map.seg, d->r_map.stride, d->r_map.off, d->r_map.inner};
@@ -627,6 +935,19 @@ int launch(const tdc_gemm_desc* d, hipStream_t st) {
             HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm256_kernel<T>,
                                               hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS));
             attr256 = true;
+        }
+        // persistent form: more tiles than CUs, identity a_map, K >= 128, in-tile byte offsets fit 32 bits
+        const int G = persistent_grid();
+        if (G > 0 && a.tiles_m * a.tiles_n > G && d->a_map.seg == 0 && d->K >= 128 &&
+            256ll * d->lda * 2 < (1ll << 31) && 256ll * d->ldw * 2 < (1ll << 31)) {
+            static bool attr256p = false;
+            if (!attr256p) {
+                HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm256p_kernel<T>,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, T2P_LDS));
+                attr256p = true;
+            }
+            hipLaunchKernelGGL(gemm256p_kernel<T>, dim3(G), dim3(512), T2P_LDS, st, a);
+            return (int)hipGetLastError();
         }
         hipLaunchKernelGGL(gemm256_kernel<T>, dim3(a.tiles_m * a.tiles_n), dim3(512), T2_LDS, st, a);
         return (int)hipGetLastError();
