@@ -75,6 +75,43 @@ def test_gemm_epilogues(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("N", [1792, 1160])
+def test_gemm_persistent(ops, dtype, N):
+    """More 256x256 tiles than CUs: the persistent kernel walks several tiles per workgroup (tile seams, epilogue beside
+    the live pipeline, lane-held bias).  Every epilogue variant, ragged M and N edges; and rows must not depend on which
+    kernel computed them (bitwise equal to a small-M launch of the same rows through the one-tile-per-workgroup kernels)."""
+    from tdc_video_amd import lib as L
+    g = torch.Generator(device="cuda").manual_seed(5)
+    M, K = 80 * 256 - 19, 192
+    a = torch.randn(M, K, device="cuda", generator=g).to(dtype)
+    w = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).to(dtype)
+    bias = torch.randn(N, device="cuda", generator=g)
+    lin = a.float() @ w.float().t() + bias
+    plain = ops.gemm(a, w, bias)
+    assert relerr(plain, lin) < tol(dtype)
+    assert relerr(ops.gemm(a, w, None), lin - bias) < tol(dtype)
+    assert relerr(ops.gemm(a, w, bias, act=L.ACT_GELU_ERF), F.gelu(lin)) < tol(dtype)
+    assert relerr(ops.gemm(a, w, bias, act=L.ACT_GELU_TANH), F.gelu(lin, approximate="tanh")) < tol(dtype)
+    sw = ops.gemm(a, w, bias, act=L.ACT_SWIGLU)
+    assert relerr(sw, F.silu(lin[:, 0::2]) * lin[:, 1::2]) < tol(dtype)
+    res32 = torch.randn(M, N, device="cuda", generator=g)
+    o32 = ops.gemm(a, w, bias, res=res32, out_f32=True)
+    assert relerr(o32, lin + res32) < tol(dtype)
+    r2 = res32.clone()
+    ops.gemm(a, w, bias, res=r2, out=r2, out_f32=True)            # in place on the residual stream
+    assert torch.equal(r2, o32)
+    assert relerr(ops.gemm(a, w, bias, out_f32=True), lin) < tol(dtype)
+    res16 = res32.to(dtype)
+    assert relerr(ops.gemm(a, w, bias, res=res16), lin + res16.float()) < tol(dtype)
+    # kernel independence: the same rows through a launch small enough for the one-tile-per-workgroup kernels
+    for lo in (0, 36 * 256 + 5, M - 300):
+        sub = ops.gemm(a[lo:lo + 300].contiguous(), w, bias)
+        assert torch.equal(sub, plain[lo:lo + 300])
+        sub32 = ops.gemm(a[lo:lo + 300].contiguous(), w, bias, res=res32[lo:lo + 300].contiguous(), out_f32=True)
+        assert torch.equal(sub32, o32[lo:lo + 300])
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_gemm_row_maps(ops, dtype):
     g = torch.Generator(device="cuda").manual_seed(2)
     F_, S, Kq, D, N = 5, 11, 4, 128, 64
