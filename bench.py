@@ -295,7 +295,7 @@ def main():
     # same GEMM launch list by the torch-free driver tools/gemm_pmc.cpp (rocprofv3 --pmc segfaults inside a torch
     # process on this image) and committed under profiles/; null when that summary is absent or another workload runs.
     traffic = mfma_busy = kv_busy = None
-    pmc = os.path.join(ROOT, "profiles", "r01c_gemm_pmc_summary.json")
+    pmc = os.path.join(ROOT, "profiles", "r01e_gemm_pmc_summary.json")
     if os.path.exists(pmc) and (T, K, H, world, args.tower_batch) == (512, 144, 3584, 1, 512):
         summ = json.load(open(pmc))
         traffic = round(summ["per_launch_hbm_bytes"])
