@@ -49,8 +49,21 @@ typedef struct {
     int M, N, K;
     int dtype, out_f32, res_f32, act;
     tdc_rowmap a_map, c_map, r_map;
+    /* LayerNorm fused into the GEMMs around it (ViT towers; all NULL = plain GEMM).
+     * Producer (the fp32 residual-stream GEMMs: out_f32, fp32 res, identity c_map / r_map, N % 64 == 0): with x16 != NULL
+     * the updated row is also written as 16-bit to x16 [rows, ldx16] and, per row m and 64-column slot s, (mean, M2) of
+     * the slot's 64 values to ln_part[(s * M + m) * 2 ..] (slot-major); tdc_ln_finalize turns them into (mean, rstd) per row.
+     * Consumer (16-bit output, no residual, identity a_map): with ln_stats != NULL, A holds the RAW rows x (x16 of the
+     * producer) and W the gamma-folded weight W diag(gamma); the epilogue computes
+     *   act(rstd[m] * (acc[m, n] - mean[m] * ln_c1[n]) + bias[n])   == act(LayerNorm(x) W^T + b)
+     * with ln_stats [M, 2] = (mean, rstd), ln_c1[n] = sum_k W'[n, k] (of the 16-bit W'), bias = beta W^T + b. */
+    void* x16; int ldx16; float* ln_part;
+    const float* ln_stats; const float* ln_c1;
 } tdc_gemm_desc;
 int tdc_gemm(const tdc_gemm_desc* d, void* stream);
+/* (mean, M2) partials [slots, rows, 2] of `slots` 64-column slots per row -> stats [rows, 2] = (mean, 1 / sqrt(var + eps)), biased
+ * variance over slots * 64 columns (nn.LayerNorm); Chan's parallel combination in a fixed order. */
+int tdc_ln_finalize(const float* ln_part, int slots, int rows, float eps, float* stats, void* stream);
 
 /* LayerNorm over `cols` real columns of x [rows, ldx] (fp32 or 16-bit), optional additive table before the norm:
  * x'[r] = x[r] + add[(r % add_period) mapped by add_mode]; y = LN(x') * gamma + beta.  Writes y16 (16-bit, pad
@@ -143,7 +156,8 @@ int tdc_qformer_embed(const tdc_qembed_desc* d, void* stream);
  * Replaces SiglipVisionTower._forward / DinoVisionTower._forward (tdc/multimodal_encoder/siglip_encoder.py:71-78,
  * dino_encoder.py:109-120) incl. the HF SiglipVisionModel / Dinov2Model they wrap: patch-embed GEMM (+pos, +cls),
  * n_layers x {LN, qkv GEMM, attention, out GEMM (+residual), LN, fc1 GEMM (+GELU-tanh / SwiGLU), fc2 GEMM (+residual)},
- * optional final LN, bilinear resample of the token grid (cls dropped).  Weights are the prepared (padded, fused,
+ * optional final LN - with `fused` the two LayerNorms of a block are not kernels: the residual-stream GEMM before them
+ * emits the 16-bit row copy + per-slot statistics and the GEMM after them folds (mean, rstd) into its epilogue -, bilinear resample of the token grid (cls dropped).  Weights are the prepared (padded, fused,
  * LayerScale-folded) tensors of tdc-video_amd/weights.py; all pointers are device pointers except `layers`
  * (host array).  The residual stream is fp32.  Nothing is allocated: the caller passes a workspace of at least
  * tdc_vit_workspace_bytes() bytes (256-byte aligned). */
@@ -151,6 +165,10 @@ typedef struct { const void* w; const float* b; int n, k; } tdc_lin;      /* w [
 typedef struct {
     const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
     tdc_lin qkv, out, fc1, fc2;
+    /* LayerNorm fusion (tdc_vit_model.fused): row sums of the gamma-folded qkv / fc1 weight (tdc_gemm_desc.ln_c1); the
+     * lin's weight is then W diag(gamma) and its bias beta W^T + b.  qkv_c1 == NULL: this layer's LN1 runs as a kernel
+     * (layer 0, whose input comes from the patch embedding). */
+    const float *qkv_c1, *fc1_c1;
 } tdc_vit_layer;
 typedef struct {
     int dtype, dim, heads, head_dim, n_layers, patch, has_cls;
@@ -161,6 +179,7 @@ typedef struct {
     const float* cls_row;            /* cls + pos[0], [pad64(dim)] (NULL when !has_cls) */
     const float *lnf_g, *lnf_b;      /* final LayerNorm (NULL: take the raw residual stream, SigLIP hidden_states[-1]) */
     const tdc_vit_layer* layers_host;
+    int fused;                       /* pre-LayerNorms folded into the qkv / fc1 GEMMs (dim % 64 == 0) */
 } tdc_vit_model;
 size_t tdc_vit_workspace_bytes(const tdc_vit_model* m, int B, int H, int W);
 /* px [B,3,H,W] (fp32 when px_f32 else 16-bit) -> out [B*out_grid*out_grid, ldo] 16-bit; idx0/idx1/frac: bilinear tables

@@ -12,7 +12,7 @@ inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline int pad64i(int x) { return (x + 63) / 64 * 64; }
 
 struct VitWs {
-    size_t patches, x32, h16, qkv, attn, mlp, total;
+    size_t patches, x32, h16, qkv, attn, mlp, part, stats, total;
 };
 
 VitWs vit_layout(const tdc_vit_model* m, int B, int H, int W) {
@@ -30,6 +30,8 @@ VitWs vit_layout(const tdc_vit_model* m, int B, int H, int W) {
     w.qkv = off;     off += al256(rows * qkv_w * 2);
     w.attn = off;    off += al256(rows * Dp * 2);
     w.mlp = off;     off += al256(rows * mlp_w * 2);
+    w.part = off;    off += m->fused ? al256(rows * (size_t)(Dp / 64) * 8) : 0;
+    w.stats = off;   off += m->fused ? al256(rows * 8) : 0;
     w.total = off;
     return w;
 }
@@ -43,6 +45,17 @@ int gemm(const void* A, int lda, const tdc_lin& L, void* C, int ldc, int M, int 
     d.A = A; d.lda = lda; d.W = L.w; d.ldw = L.k; d.C = C; d.ldc = ldc; d.bias = L.b; d.res = res; d.ldres = ldres;
     d.M = M; d.N = L.n; d.K = L.k; d.dtype = dtype; d.out_f32 = out_f32; d.res_f32 = res_f32; d.act = act;
     d.c_map = cmap; d.r_map = rmap;
+    return tdc_gemm(&d, st);
+}
+
+// tdc_gemm with the LayerNorm-fusion operands (identity row maps): producer side x16 / part, consumer side stats / c1
+int gemm_ln(const void* A, int lda, const tdc_lin& L, void* C, int ldc, int M, int dtype, int act, int out_f32,
+            const void* res, int ldres, void* x16, int ldx16, float* part, const float* stats, const float* c1, void* st) {
+    tdc_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.A = A; d.lda = lda; d.W = L.w; d.ldw = L.k; d.C = C; d.ldc = ldc; d.bias = L.b; d.res = res; d.ldres = ldres;
+    d.M = M; d.N = L.n; d.K = L.k; d.dtype = dtype; d.out_f32 = out_f32; d.res_f32 = res ? 1 : 0; d.act = act;
+    d.x16 = x16; d.ldx16 = ldx16; d.ln_part = part; d.ln_stats = stats; d.ln_c1 = c1;
     return tdc_gemm(&d, st);
 }
 
@@ -230,10 +243,22 @@ extern "C" int tdc_vit_fwd(const tdc_vit_model* m, const void* px, int px_f32, i
         if (e != hipSuccess) return (int)e;
     }
     const float scale = 1.0f / sqrtf((float)m->head_dim);
+    // fused: the block's LayerNorms are folded into the GEMMs around them (tdc_gemm_desc: x16 / ln_part / ln_stats / ln_c1);
+    // h16 then holds the 16-bit copy of the residual stream instead of the LayerNorm output
+    const bool fused = m->fused != 0;
+    if (fused && (D % 64 != 0)) return TDC_E_BADARG;
+    float* part = (float*)(ws + w.part);
+    float* stats = (float*)(ws + w.stats);
+    const int slots = D / 64;
     for (int l = 0; l < m->n_layers; ++l) {
         const tdc_vit_layer& L = m->layers_host[l];
-        RET_IF(layernorm(x32, Dp, h16, Dp, L.ln1_g, L.ln1_b, m->eps, rows, D, dt, stream));
-        RET_IF(gemm(h16, Dp, L.qkv, qkv, L.qkv.n, rows, dt, TDC_ACT_NONE, 0, nullptr, 0, 0, ident, ident, stream));
+        if (!fused || !L.qkv_c1) {
+            RET_IF(layernorm(x32, Dp, h16, Dp, L.ln1_g, L.ln1_b, m->eps, rows, D, dt, stream));
+            RET_IF(gemm(h16, Dp, L.qkv, qkv, L.qkv.n, rows, dt, TDC_ACT_NONE, 0, nullptr, 0, 0, ident, ident, stream));
+        } else {
+            RET_IF(gemm_ln(h16, Dp, L.qkv, qkv, L.qkv.n, rows, dt, TDC_ACT_NONE, 0, nullptr, 0, nullptr, 0, nullptr, stats,
+                           L.qkv_c1, stream));
+        }
         tdc_attn_desc a;
         memset(&a, 0, sizeof(a));
         const long long bs = (long long)S * L.qkv.n;
@@ -242,10 +267,25 @@ extern "C" int tdc_vit_fwd(const tdc_vit_model* m, const void* px, int px_f32, i
         a.q_rs = a.k_rs = a.v_rs = L.qkv.n; a.o_rs = Dp;
         a.batch = B; a.heads = m->heads; a.head_dim = m->head_dim; a.sq = S; a.sk = S; a.scale = scale; a.dtype = dt;
         RET_IF(tdc_attention(&a, stream));
-        RET_IF(gemm(attn, Dp, L.out, x32, Dp, rows, dt, TDC_ACT_NONE, 1, x32, Dp, 1, ident, ident, stream));
-        RET_IF(layernorm(x32, Dp, h16, Dp, L.ln2_g, L.ln2_b, m->eps, rows, D, dt, stream));
-        RET_IF(gemm(h16, Dp, L.fc1, mlp, L.fc2.k, rows, dt, m->act, 0, nullptr, 0, 0, ident, ident, stream));
-        RET_IF(gemm(mlp, L.fc2.k, L.fc2, x32, Dp, rows, dt, TDC_ACT_NONE, 1, x32, Dp, 1, ident, ident, stream));
+        if (fused) {
+            RET_IF(gemm_ln(attn, Dp, L.out, x32, Dp, rows, dt, TDC_ACT_NONE, 1, x32, Dp, h16, Dp, part, nullptr, nullptr,
+                           stream));
+            RET_IF(tdc_ln_finalize(part, slots, rows, m->eps, stats, stream));
+            RET_IF(gemm_ln(h16, Dp, L.fc1, mlp, L.fc2.k, rows, dt, m->act, 0, nullptr, 0, nullptr, 0, nullptr, stats,
+                           L.fc1_c1, stream));
+            if (l + 1 < m->n_layers) {
+                RET_IF(gemm_ln(mlp, L.fc2.k, L.fc2, x32, Dp, rows, dt, TDC_ACT_NONE, 1, x32, Dp, h16, Dp, part, nullptr,
+                               nullptr, stream));
+                RET_IF(tdc_ln_finalize(part, slots, rows, m->eps, stats, stream));
+            } else {
+                RET_IF(gemm(mlp, L.fc2.k, L.fc2, x32, Dp, rows, dt, TDC_ACT_NONE, 1, x32, Dp, 1, ident, ident, stream));
+            }
+        } else {
+            RET_IF(gemm(attn, Dp, L.out, x32, Dp, rows, dt, TDC_ACT_NONE, 1, x32, Dp, 1, ident, ident, stream));
+            RET_IF(layernorm(x32, Dp, h16, Dp, L.ln2_g, L.ln2_b, m->eps, rows, D, dt, stream));
+            RET_IF(gemm(h16, Dp, L.fc1, mlp, L.fc2.k, rows, dt, m->act, 0, nullptr, 0, 0, ident, ident, stream));
+            RET_IF(gemm(mlp, L.fc2.k, L.fc2, x32, Dp, rows, dt, TDC_ACT_NONE, 1, x32, Dp, 1, ident, ident, stream));
+        }
     }
     const void* src = x32;
     int src_f32 = 1;

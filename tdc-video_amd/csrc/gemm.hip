@@ -32,6 +32,9 @@ struct GemmArgs {
     RowMap am, cm, rm;
     int tiles_m, tiles_n;
     int debug;   // TDC_GEMM_DEBUG: 1 = skip the epilogue, 2 = direct (un-staged) epilogue - timing experiments only
+    // LayerNorm fusion (see EpiOps / slot_stats_*): producer side x16 + ln_part, consumer side ln_stats + ln_c1
+    void* x16; int ldx16; float* ln_part;
+    const float* ln_stats; const float* ln_c1;
 #ifdef TDC_GEMM_DIAG
     unsigned long long* stamps;   // diagnostics build only (tools/gemm_stamps.cpp): 8 x u64 per workgroup
 #endif
@@ -56,37 +59,133 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
-// Bias vectors of a wave's 64 columns in the MFMA layout (lane (fr, g) needs columns j*16 + 4g .. +3 of column tile j).
-// LANE = false: loaded from global memory here.  LANE = true (persistent kernel): lane L already holds bias[nbase + L]
-// in `bias_lane` (loaded one tile ahead, so that no vector-memory load - whose in-order vmcnt wait would also wait for
-// the next tile's staged operands - sits at the start of the epilogue); the vectors are gathered with ds_bpermute.
-template <bool LANE, int NJ>
-__device__ __forceinline__ void get_bias(const GemmArgs& p, int nbase, int lane, float bias_lane, f32x4 (&bias)[NJ]) {
-    const int g = lane >> 4;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        if (LANE) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                bias[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((j * 16 + g * 4 + e) * 4,
-                                                                                    __builtin_bit_cast(int, bias_lane)));
-        } else {
-            const int n = nbase + j * 16 + g * 4;
-            bias[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (p.bias && n < p.N) bias[j] = *(const f32x4*)(p.bias + n);
-        }
-    }
+// ---- epilogue operands ----------------------------------------------------------------------------------------------
+// Per-column / per-row operands of a wave's sub-tile in the MFMA layout: lane (fr, g) holds, per accumulator tile (i, j),
+// row 16 i + fr and columns 16 j + 4 g .. +3.
+//   bias[j]          - the nn.Linear bias (LayerNorm fusion: beta . W^T + b);
+//   c1[j], mean[i], rstd[i] (FOLD) - LayerNorm fused into the consumer GEMM: A holds the RAW 16-bit rows x, W the
+//                      gamma-folded weight W' = W diag(gamma); LN(x) W^T + b == rstd (x W'^T - mean c1) + bias with
+//                      c1[n] = sum_k W'[n, k]; (mean, rstd) of row m come from ln_stats [M, 2] (tdc_ln_finalize).
+// In the persistent kernel these values are already in registers, one column / row per lane (EpiLane, loaded one tile
+// ahead so that no vector-memory load - whose in-order vmcnt wait would also wait for the next tile's staged operands -
+// sits at the start of the epilogue) and are gathered with ds_bpermute; the other kernels load them here.
+struct EpiLane {
+    float bias, c1;        // column nbase + lane
+    float mean0, rstd0;    // row mbase + lane
+    float mean1, rstd1;    // row mbase + 64 + lane
+};
+
+__device__ __forceinline__ float lane_get(float v, int src_lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane * 4, __builtin_bit_cast(int, v)));
 }
 
-// ---- epilogue -------------------------------------------------------------------------------------------------------
+template <int MI, int NJ, bool LANE, bool FOLD>
+struct EpiOps {
+    f32x4 bias[NJ], c1[NJ];
+    float mean[MI], rstd[MI];
+    __device__ __forceinline__ void load(const GemmArgs& p, int mbase, int nbase, int fr, int g, const EpiLane& el) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (LANE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bias[j][e] = lane_get(el.bias, j * 16 + g * 4 + e);
+                    if (FOLD) c1[j][e] = lane_get(el.c1, j * 16 + g * 4 + e);
+                }
+            } else {
+                const int n = nbase + j * 16 + g * 4;
+                bias[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (FOLD) c1[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (n < p.N) {
+                    if (p.bias) bias[j] = *(const f32x4*)(p.bias + n);
+                    if (FOLD) c1[j] = *(const f32x4*)(p.ln_c1 + n);
+                }
+            }
+        }
+        if (FOLD) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                if (LANE) {
+                    const int r = (i & 3) * 16 + fr;
+                    mean[i] = lane_get(i < 4 ? el.mean0 : el.mean1, r);
+                    rstd[i] = lane_get(i < 4 ? el.rstd0 : el.rstd1, r);
+                } else {
+                    int m = mbase + i * 16 + fr;
+                    if (m > p.M - 1) m = p.M - 1;
+                    const float2 st = *(const float2*)(p.ln_stats + 2 * (long long)m);
+                    mean[i] = st.x; rstd[i] = st.y;
+                }
+            }
+        }
+    }
+    // the linear output of accumulator tile (i, j).  FOLD: two explicit fmas per element - the same instruction sequence
+    // in every kernel and layout (a row must not depend on which kernel computed it)
+    __device__ __forceinline__ f32x4 lin(f32x4 acc, int i, int j) const {
+        if (!FOLD) return acc + bias[j];
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            r[e] = __builtin_fmaf(rstd[i], __builtin_fmaf(-mean[i], c1[j][e], acc[e]), bias[j][e]);
+        return r;
+    }
+};
+
+// ---- LayerNorm fusion, producer side: (mean, M2) of one row x 64-column slot --------------------------------------------
+// The fp32 residual-stream GEMMs (out-projection, fc2) also write the updated row as 16-bit (x16, the next GEMM's A
+// operand) and, per row and 64-column slot, the slot's mean and sum of squared deviations; tdc_ln_finalize combines the
+// N/64 slots of a row (Chan) into (mean, rstd).  The two layouts below run the SAME balanced tree over the 16 four-column
+// groups c = 0..15 of a slot (pairs c^1, c^2, c^4, c^8 in that order, no fp contraction), so the partials - like every
+// other output - are bit-identical whichever kernel computes a row.
+#pragma clang fp contract(off)
+// staged layout: the 16 lanes of a row segment hold groups c = lane & 15 (DPP exchanges inside the 16-lane row)
+__device__ __forceinline__ float row16_xch(float v, int level) {
+    const int x = __builtin_bit_cast(int, v);
+    int r;
+    if (level == 0) r = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
+    else if (level == 1) r = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    else if (level == 2) r = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false);  // row_half_mirror
+    else r = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false);                  // row_mirror
+    return __builtin_bit_cast(float, r);
+}
+__device__ __forceinline__ void slot_stats_row16(f32x4 v, float& mean, float& m2) {
+    float s = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+    for (int l = 0; l < 4; ++l) s = s + row16_xch(s, l);
+    mean = s * 0.015625f;
+    const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+    float q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+#pragma unroll
+    for (int l = 0; l < 4; ++l) q = q + row16_xch(q, l);
+    m2 = q;
+}
+// MFMA layout: group c = 4 j + g: g across the lanes l ^ 16, l ^ 32, j across the four accumulator tiles of the row
+__device__ __forceinline__ void slot_stats_mfma(const f32x4 (&v)[4], float& mean, float& m2) {
+    float s[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s[j] = (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        s[j] = s[j] + __shfl_xor(s[j], 16);
+        s[j] = s[j] + __shfl_xor(s[j], 32);
+    }
+    mean = ((s[0] + s[1]) + (s[2] + s[3])) * 0.015625f;
+    float q[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float d0 = v[j][0] - mean, d1 = v[j][1] - mean, d2 = v[j][2] - mean, d3 = v[j][3] - mean;
+        q[j] = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        q[j] = q[j] + __shfl_xor(q[j], 16);
+        q[j] = q[j] + __shfl_xor(q[j], 32);
+    }
+    m2 = (q[0] + q[1]) + (q[2] + q[3]);
+}
+#pragma clang fp contract(fast)
+
+// ---- epilogue, MFMA layout (128^2 kernel; fallback of the 256^2 kernels) ---------------------------------------------------
 // Each lane holds, per (i, j) accumulator tile, 4 consecutive output columns n..n+3 of ONE output row m.  The epilogue
-// is specialised at compile time on (activation, residual kind, output type): the run-time flags select one of the
-// branch-free instantiations once per kernel, so bias vectors are loaded once per column tile and the residual
-// loads / stores of a row issue back to back instead of waiting on each other.
+// is specialised at compile time on (activation, residual kind, output type, LayerNorm fusion): the run-time flags select
+// one of the branch-free instantiations once per kernel.
 template <class T, int ACT, int RES, bool OUTF32>
-__device__ __forceinline__ void epi_store(const GemmArgs& p, f32x4 v, f32x4 bias, long long crow, long long rrow,
-                                          int n) {
-    v += bias;
+__device__ __forceinline__ void epi_store(const GemmArgs& p, f32x4 v, long long crow, long long rrow, int n) {
     if (ACT == TDC_ACT_GELU_ERF) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
@@ -124,11 +223,11 @@ __device__ __forceinline__ void epi_store(const GemmArgs& p, f32x4 v, f32x4 bias
     }
 }
 
-template <class T, int MI, int NJ, int ACT, int RES, bool OUTF32, bool LB>
+template <class T, int MI, int NJ, int ACT, int RES, bool OUTF32, bool LB, bool FOLD>
 __device__ __forceinline__ void epi_tile(const GemmArgs& p, f32x4 (&acc)[MI][NJ], int mbase, int nbase, int fr,
-                                         int g, float bias_lane) {
-    f32x4 bias[NJ];
-    get_bias<LB, NJ>(p, nbase, fr + g * 16, bias_lane, bias);
+                                         int g, const EpiLane& el) {
+    EpiOps<MI, NJ, LB, FOLD> ops;
+    ops.load(p, mbase, nbase, fr, g, el);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = mbase + i * 16 + fr;
@@ -138,28 +237,73 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& p, f32x4 (&acc)[MI][NJ]
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int n = nbase + j * 16 + g * 4;
-                if (n < p.N) epi_store<T, ACT, RES, OUTF32>(p, acc[i][j], bias[j], crow, rrow, n);
+                if (n < p.N) epi_store<T, ACT, RES, OUTF32>(p, ops.lin(acc[i][j], i, j), crow, rrow, n);
             }
         }
     }
 }
 
+// fp32 residual stream update + 16-bit copy + per-slot LayerNorm partials (N % 64 == 0, identity c_map / r_map)
+template <class T, int MI, bool LB>
+__device__ __forceinline__ void epi_tile_emit(const GemmArgs& p, f32x4 (&acc)[MI][4], int mbase, int nbase, int fr,
+                                              int g, const EpiLane& el) {
+    typedef typename VecOf<T>::v4 v4;
+    if (nbase >= p.N) return;                       // wave-uniform
+    EpiOps<MI, 4, LB, false> ops;
+    ops.load(p, mbase, nbase, fr, g, el);
+    const int slot = nbase >> 6;      // partials are slot-major: ln_part[slot][M][2]
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = mbase + i * 16 + fr;
+        const int mc = m < p.M ? m : p.M - 1;       // clamped rows compute (the exchanges need every lane), never store
+        f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = nbase + j * 16 + g * 4;
+            v[j] = ops.lin(acc[i][j], i, j) + *(const f32x4*)((const float*)p.res + (long long)mc * p.ldres + n);
+        }
+        float mean, m2;
+        slot_stats_mfma(v, mean, m2);
+        if (m < p.M) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = nbase + j * 16 + g * 4;
+                *(f32x4*)((float*)p.C + (long long)m * p.ldc + n) = v[j];
+                v4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (T)v[j][e];
+                *(v4*)((T*)p.x16 + (long long)m * p.ldx16 + n) = o;
+            }
+            if (g == 0) *(float2*)(p.ln_part + 2 * ((long long)slot * p.M + m)) = make_float2(mean, m2);
+        }
+    }
+}
+
+template <class T, int MI, int NJ, bool LB, bool FOLD>
+__device__ __forceinline__ void epilogue_f(const GemmArgs& p, f32x4 (&acc)[MI][NJ], int mbase, int nbase, int fr, int g,
+                                           const EpiLane& el) {
+    const int res = p.res ? (p.res_f32 ? 1 : 2) : 0;
+    if (p.act == TDC_ACT_GELU_ERF) epi_tile<T, MI, NJ, TDC_ACT_GELU_ERF, 0, false, LB, FOLD>(p, acc, mbase, nbase, fr, g, el);
+    else if (p.act == TDC_ACT_GELU_TANH) epi_tile<T, MI, NJ, TDC_ACT_GELU_TANH, 0, false, LB, FOLD>(p, acc, mbase, nbase, fr, g, el);
+    else if (p.act == TDC_ACT_SWIGLU) epi_tile<T, MI, NJ, TDC_ACT_SWIGLU, 0, false, LB, FOLD>(p, acc, mbase, nbase, fr, g, el);
+    else if (!p.out_f32 && res == 0) epi_tile<T, MI, NJ, 0, 0, false, LB, FOLD>(p, acc, mbase, nbase, fr, g, el);
+    else if (FOLD) return;                          // (host-checked: the fold only exists for 16-bit outputs without residual)
+    else if (p.out_f32) {
+        if (res == 1) epi_tile<T, MI, NJ, 0, 1, true, LB, false>(p, acc, mbase, nbase, fr, g, el);
+        else if (res == 2) epi_tile<T, MI, NJ, 0, 2, true, LB, false>(p, acc, mbase, nbase, fr, g, el);
+        else epi_tile<T, MI, NJ, 0, 0, true, LB, false>(p, acc, mbase, nbase, fr, g, el);
+    } else {
+        if (res == 1) epi_tile<T, MI, NJ, 0, 1, false, LB, false>(p, acc, mbase, nbase, fr, g, el);
+        else epi_tile<T, MI, NJ, 0, 2, false, LB, false>(p, acc, mbase, nbase, fr, g, el);
+    }
+}
+
 template <class T, int MI, int NJ, bool LB = false>
 __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[MI][NJ], int mbase, int nbase, int fr, int g,
-                                         float bias_lane = 0.f) {
-    const int res = p.res ? (p.res_f32 ? 1 : 2) : 0;
-    if (p.act == TDC_ACT_GELU_ERF) epi_tile<T, MI, NJ, TDC_ACT_GELU_ERF, 0, false, LB>(p, acc, mbase, nbase, fr, g, bias_lane);
-    else if (p.act == TDC_ACT_GELU_TANH) epi_tile<T, MI, NJ, TDC_ACT_GELU_TANH, 0, false, LB>(p, acc, mbase, nbase, fr, g, bias_lane);
-    else if (p.act == TDC_ACT_SWIGLU) epi_tile<T, MI, NJ, TDC_ACT_SWIGLU, 0, false, LB>(p, acc, mbase, nbase, fr, g, bias_lane);
-    else if (p.out_f32) {
-        if (res == 1) epi_tile<T, MI, NJ, 0, 1, true, LB>(p, acc, mbase, nbase, fr, g, bias_lane);
-        else if (res == 2) epi_tile<T, MI, NJ, 0, 2, true, LB>(p, acc, mbase, nbase, fr, g, bias_lane);
-        else epi_tile<T, MI, NJ, 0, 0, true, LB>(p, acc, mbase, nbase, fr, g, bias_lane);
-    } else {
-        if (res == 1) epi_tile<T, MI, NJ, 0, 1, false, LB>(p, acc, mbase, nbase, fr, g, bias_lane);
-        else if (res == 2) epi_tile<T, MI, NJ, 0, 2, false, LB>(p, acc, mbase, nbase, fr, g, bias_lane);
-        else epi_tile<T, MI, NJ, 0, 0, false, LB>(p, acc, mbase, nbase, fr, g, bias_lane);
-    }
+                                         const EpiLane& el = EpiLane()) {
+    if (NJ == 4 && p.x16) { epi_tile_emit<T, MI, LB>(p, (f32x4 (&)[MI][4])acc, mbase, nbase, fr, g, el); return; }
+    if (!LB && p.ln_stats) epilogue_f<T, MI, NJ, LB, true>(p, acc, mbase, nbase, fr, g, el);   // lane-held: LNF kernel
+    else epilogue_f<T, MI, NJ, LB, false>(p, acc, mbase, nbase, fr, g, el);
 }
 
 // tile id -> (tile_m, tile_n), "grouped" order: ids walk GROUP_M tile rows column by column before moving to the next
@@ -258,22 +402,23 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     epilogue<T, 4, 4>(p, acc, m0 + wm * 64, n0 + wn_ * 64, fr, g);
 }
 
-// ---- LDS-staged epilogue of the 256^2 kernel --------------------------------------------------------------------------
+// ---- LDS-staged epilogue of the 256^2 kernels -------------------------------------------------------------------------
 // Row-per-lane stores straight from the MFMA layout touch 16 cache lines with 8 B each per instruction and are
 // store-ISSUE bound (~7 B/clk/CU, cdna_hip_programming.md T21): the 128 KiB C tile cost ~9 us per workgroup, 25 % of a
-// K=1152 GEMM.  Instead every wave transposes its 128x64 sub-tile through its own 16 KiB of the (now idle) pipeline LDS
-// and stores whole rows: one instruction = 8 rows x 128 B (16-bit out) or 4 rows x 256 B (fp32 out), 16 B per lane.
-// Bias / activation run before staging (MFMA layout, one bias vector per column tile); the fp32 residual add runs
-// after it, on full 256-B row segments.  XOR swizzle of the 16-B chunk with the row keeps both sides (nearly) conflict-free.
-template <class T, int ACT, int RES, int ROWS, bool LB>
+// K=1152 GEMM.  Instead every wave transposes its 128x64 sub-tile through LDS (its own 16 KiB of the idle pipeline
+// buffers; 4 KiB beside the live pipeline in the persistent kernel: ROWS rows per pass) and stores whole rows: one
+// instruction = 8 rows x 128 B (16-bit out) or 4 rows x 256 B (fp32 out), 16 B per lane.  Bias / LayerNorm fold /
+// activation run before staging (MFMA layout); the fp32 residual add runs after it, on full 256-B row segments.  XOR
+// swizzle of the 16-B chunk with the row keeps both sides (nearly) conflict-free.
+template <class T, int ACT, int RES, int ROWS, bool LB, bool FOLD>
 __device__ __forceinline__ void epi_staged16(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase, int nbase,
-                                             int lane, float bias_lane) {
+                                             int lane, const EpiLane& el) {
     // ROWS = rows of the wave's 128x64 sub-tile staged per pass (128-byte rows): 128 (16 KiB region) or 32 (4 KiB)
     typedef typename VecOf<T>::v4 v4;
     typedef typename VecOf<T>::v8 v8;
     const int fr = lane & 15, g = lane >> 4;
-    f32x4 bias[4];
-    get_bias<LB, 4>(p, nbase, lane, bias_lane, bias);
+    EpiOps<8, 4, LB, FOLD> ops;
+    ops.load(p, mbase, nbase, fr, g, el);
 #pragma unroll
     for (int pass = 0; pass < 128 / ROWS; ++pass) {
 #pragma unroll
@@ -285,7 +430,7 @@ __device__ __forceinline__ void epi_staged16(const GemmArgs& p, f32x4 (&acc)[8][
             if (RES == 2) rrow = p.rm(m < p.M ? m : p.M - 1);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                f32x4 v = acc[i][j] + bias[j];
+                f32x4 v = ops.lin(acc[i][j], i, j);
                 if (ACT == TDC_ACT_GELU_ERF) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
@@ -323,14 +468,14 @@ __device__ __forceinline__ void epi_staged16(const GemmArgs& p, f32x4 (&acc)[8][
 // SwiGLU: columns are interleaved (x1_j, x2_j); each lane produces 2 outputs per accumulator tile, the wave's 128x64
 // sub-tile becomes 128 rows x 32 outputs (64-byte rows, 8 KiB).  Staging turns 32 four-byte stores per lane (16 rows
 // x 16 B per instruction) into 8 sixteen-byte stores (16 rows x 64 B per instruction).
-template <class T, int ROWS, bool LB>
+template <class T, int ROWS, bool LB, bool FOLD>
 __device__ __forceinline__ void epi_staged_swiglu(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase,
-                                                  int nbase, int lane, float bias_lane) {
+                                                  int nbase, int lane, const EpiLane& el) {
     typedef __attribute__((ext_vector_type(2))) T v2;
     typedef typename VecOf<T>::v8 v8;
     const int fr = lane & 15, g = lane >> 4;
-    f32x4 bias[4];
-    get_bias<LB, 4>(p, nbase, lane, bias_lane, bias);
+    EpiOps<8, 4, LB, FOLD> ops;
+    ops.load(p, mbase, nbase, fr, g, el);
 #pragma unroll
     for (int pass = 0; pass < 128 / ROWS; ++pass) {
 #pragma unroll
@@ -339,7 +484,7 @@ __device__ __forceinline__ void epi_staged_swiglu(const GemmArgs& p, f32x4 (&acc
             const int r = ii * 16 + fr;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const f32x4 v = acc[i][j] + bias[j];
+                const f32x4 v = ops.lin(acc[i][j], i, j);
                 v2 o;
                 o[0] = (T)(silu(v[0]) * v[1]);
                 o[1] = (T)(silu(v[2]) * v[3]);
@@ -358,13 +503,16 @@ __device__ __forceinline__ void epi_staged_swiglu(const GemmArgs& p, f32x4 (&acc
     }
 }
 
-template <class T, int RES, int ROWS, bool LB>
+// fp32 output (+ fp32 residual).  EMIT (LayerNorm fusion, producer side): the updated row also goes out as 16-bit
+// (x16) together with the per-slot (mean, M2) partials - identity row maps, N % 64 == 0.
+template <class T, int RES, int ROWS, bool LB, bool EMIT>
 __device__ __forceinline__ void epi_staged32(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase, int nbase,
-                                             int lane, float bias_lane) {
+                                             int lane, const EpiLane& el) {
     // ROWS = rows staged per pass (256-byte fp32 rows): 64 (16 KiB region) or 16 (4 KiB)
+    typedef typename VecOf<T>::v4 v4;
     const int fr = lane & 15, g = lane >> 4;
-    f32x4 bias[4];
-    get_bias<LB, 4>(p, nbase, lane, bias_lane, bias);
+    EpiOps<8, 4, LB, false> ops;
+    ops.load(p, mbase, nbase, fr, g, el);
     constexpr int NPASS = 128 / ROWS, QP = ROWS / 4;      // QP read-back instructions (4 rows x 256 B each) per pass
     // The residual loads run as a ring of RING loads ahead of the read-back, independent of the staging passes (they
     // touch no LDS); they come from clamped (always valid) addresses so that no branch - and no vmcnt(0) - separates them.
@@ -381,6 +529,7 @@ __device__ __forceinline__ void epi_staged32(const GemmArgs& p, f32x4 (&acc)[8][
 #pragma unroll
         for (int u = 0; u < RING; ++u) rr[u] = load_res(u);
     }
+    const int slot = nbase >> 6;      // partials are slot-major: ln_part[slot][M][2]
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
 #pragma unroll
@@ -389,7 +538,8 @@ __device__ __forceinline__ void epi_staged32(const GemmArgs& p, f32x4 (&acc)[8][
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int chunk = (j * 4 + g) ^ (r & 15);
-                *(f32x4*)(region + r * 256 + chunk * 16) = acc[pass * (ROWS / 16) + ii][j] + bias[j];
+                const int i = pass * (ROWS / 16) + ii;
+                *(f32x4*)(region + r * 256 + chunk * 16) = ops.lin(acc[i][j], i, j);
             }
         }
 #pragma unroll
@@ -403,36 +553,58 @@ __device__ __forceinline__ void epi_staged32(const GemmArgs& p, f32x4 (&acc)[8][
                 if (u + RING < 32) rr[u % RING] = load_res(u + RING);
             }
             if (m < p.M && n < p.N) __builtin_nontemporal_store(val, (f32x4*)((float*)p.C + p.cm(m) * p.ldc + n));
+            if (EMIT) {
+                float mean, m2;
+                slot_stats_row16(val, mean, m2);          // every lane takes part (rows beyond M: clamped duplicates)
+                if (m < p.M) {
+                    v4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (T)val[e];
+                    *(v4*)((T*)p.x16 + (long long)m * p.ldx16 + n) = o;
+                    if (k == 0) *(float2*)(p.ln_part + 2 * ((long long)slot * p.M + m)) = make_float2(mean, m2);
+                }
+            }
         }
     }
 }
 
 // returns false when this (act, res, out) combination / alignment has no staged variant.  SMALL: 4 KiB staging region
-// per wave (the persistent kernel stages beside the live pipeline buffers), otherwise 16 KiB (the idle pipeline LDS).
-template <class T, bool SMALL>
-__device__ __forceinline__ bool epilogue_staged(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase,
-                                                int nbase, int lane, float bias_lane = 0.f) {
+// per wave (the persistent kernel stages beside the live pipeline buffers, lane-held operands), otherwise 16 KiB.
+template <class T, bool SMALL, bool FOLD>
+__device__ __forceinline__ bool epilogue_staged_f(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase,
+                                                  int nbase, int lane, const EpiLane& el) {
     const int res = p.res ? (p.res_f32 ? 1 : 2) : 0;
-    constexpr int R16 = SMALL ? 32 : 128, RSW = SMALL ? 64 : 128, R32 = SMALL ? 16 : 64;
-    if (p.out_f32) {
-        if (p.act != TDC_ACT_NONE || res == 2) return false;
-        if (res == 1) epi_staged32<T, 1, R32, SMALL>(p, acc, region, mbase, nbase, lane, bias_lane);
-        else epi_staged32<T, 0, R32, SMALL>(p, acc, region, mbase, nbase, lane, bias_lane);
-        return true;
-    }
-    if (res == 1 || (p.ldc & 7) || ((uintptr_t)p.C & 15)) return false;
+    constexpr int R16 = SMALL ? 32 : 128, RSW = SMALL ? 64 : 128;
+    if (p.out_f32 || res == 1 || (p.ldc & 7) || ((uintptr_t)p.C & 15)) return false;
     if (p.act == TDC_ACT_SWIGLU) {
         if (p.N & 15) return false;
-        epi_staged_swiglu<T, RSW, SMALL>(p, acc, region, mbase, nbase, lane, bias_lane);
+        epi_staged_swiglu<T, RSW, SMALL, FOLD>(p, acc, region, mbase, nbase, lane, el);
         return true;
     }
     if (p.N & 7) return false;
-    if (p.act == TDC_ACT_GELU_ERF) epi_staged16<T, TDC_ACT_GELU_ERF, 0, R16, SMALL>(p, acc, region, mbase, nbase, lane, bias_lane);
-    else if (p.act == TDC_ACT_GELU_TANH) epi_staged16<T, TDC_ACT_GELU_TANH, 0, R16, SMALL>(p, acc, region, mbase, nbase, lane, bias_lane);
-    else if (res == 2) epi_staged16<T, 0, 2, R16, SMALL>(p, acc, region, mbase, nbase, lane, bias_lane);
-    else epi_staged16<T, 0, 0, R16, SMALL>(p, acc, region, mbase, nbase, lane, bias_lane);
+    if (p.act == TDC_ACT_GELU_ERF) epi_staged16<T, TDC_ACT_GELU_ERF, 0, R16, SMALL, FOLD>(p, acc, region, mbase, nbase, lane, el);
+    else if (p.act == TDC_ACT_GELU_TANH) epi_staged16<T, TDC_ACT_GELU_TANH, 0, R16, SMALL, FOLD>(p, acc, region, mbase, nbase, lane, el);
+    else if (res == 2) { if (FOLD) return false; epi_staged16<T, 0, 2, R16, SMALL, false>(p, acc, region, mbase, nbase, lane, el); }
+    else epi_staged16<T, 0, 0, R16, SMALL, FOLD>(p, acc, region, mbase, nbase, lane, el);
     return true;
 }
+
+template <class T, bool SMALL>
+__device__ __forceinline__ bool epilogue_staged(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase,
+                                                int nbase, int lane, const EpiLane& el = EpiLane()) {
+    constexpr int R32 = SMALL ? 16 : 64;
+    if (p.out_f32) {
+        const int res = p.res ? (p.res_f32 ? 1 : 2) : 0;
+        if (p.act != TDC_ACT_NONE || res == 2) return false;
+        if (p.x16) epi_staged32<T, 1, R32, SMALL, true>(p, acc, region, mbase, nbase, lane, el);
+        else if (res == 1) epi_staged32<T, 1, R32, SMALL, false>(p, acc, region, mbase, nbase, lane, el);
+        else epi_staged32<T, 0, R32, SMALL, false>(p, acc, region, mbase, nbase, lane, el);
+        return true;
+    }
+    if (!SMALL && p.ln_stats) return epilogue_staged_f<T, SMALL, true>(p, acc, region, mbase, nbase, lane, el);
+    return epilogue_staged_f<T, SMALL, false>(p, acc, region, mbase, nbase, lane, el);
+}
+
 
 // ======================================================================================================================
 // 256x256x64 tile, 8 waves (2 M x 4 N, 128x64 per wave), 128 KiB LDS, "8-phase" schedule (cdna_hip_programming.md
@@ -653,7 +825,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 // operands already in LDS.  Staging addresses are an SGPR tile base + 32-bit per-lane offsets (a_map must be identity).
 constexpr int T2P_LDS = T2_LDS + 8 * 4096;    // 160 KiB
 
-template <class T>
+template <class T, bool LNF>      // LNF: LayerNorm-fold consumer (ln_stats != NULL): 5 more lane-held epilogue operands
 __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
     typedef typename VecOf<T>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -783,14 +955,28 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
     int tm, tn;
     tile_coords(id, p.tiles_m, p.tiles_n, tm, tn);
     int m0 = tm * 256, n0 = tn * 256;
-    // lane L keeps bias[n0 + wn*64 + L] of the tile being computed (see get_bias); the first one is waited for here,
-    // compiler-visibly, before any staging load is in flight
-    auto load_bias_lane = [&](int n0_) {
+    // lane L keeps the epilogue operands of the tile being computed (EpiLane: column n0 + wn*64 + L, rows m0 + wm*128 +
+    // L and + 64 + L); the first set is waited for here, compiler-visibly, before any staging load is in flight
+    auto load_epi_lane = [&](int m0_, int n0_) {
+        EpiLane e = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         int n = n0_ + wn_ * 64 + lane;
         if (n > p.N - 1) n = p.N - 1;
-        return p.bias ? p.bias[n] : 0.f;
+        if (p.bias) e.bias = p.bias[n];
+        if (LNF) {
+            e.c1 = p.ln_c1[n];
+            int r0 = m0_ + wm * 128 + lane, r1 = r0 + 64;
+            if (r0 > p.M - 1) r0 = p.M - 1;
+            if (r1 > p.M - 1) r1 = p.M - 1;
+            const float2 s0 = *(const float2*)(p.ln_stats + 2 * (long long)r0);
+            const float2 s1 = *(const float2*)(p.ln_stats + 2 * (long long)r1);
+            e.mean0 = s0.x; e.rstd0 = s0.y; e.mean1 = s1.x; e.rstd1 = s1.y;
+        }
+        return e;
     };
-    float bias_lane = load_bias_lane(n0);
+    // Between its load (one tile ahead, at the start of the previous epilogue) and its use the set is parked in the wave's
+    // epilogue staging region, which is idle during the main loop: no VGPR stays live across the K loop for it.
+    EpiLane* el_park = (EpiLane*)(smem + T2_LDS + wave * 4096) + lane;
+    *el_park = load_epi_lane(m0, n0);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     // ---- prologue of the first tile: K tile 0 complete + K tile 1's A0 B0 B1
     set_stage_tile(m0, n0);
@@ -844,11 +1030,17 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
         // next tile's staged loads in the in-order vmcnt queue).
         int elane = lane;
         asm volatile("" : "+v"(elane));
-        const float next_bias_lane = more ? load_bias_lane(n1) : 0.f;    // complete by the vmcnt(0) below
+        const EpiLane el = *el_park;
+        EpiLane el_next = el;
+        if (more) el_next = load_epi_lane(m1, n1);                       // complete by the vmcnt(0) below
         if (wave_active && p.debug != 1) {
-            if (!epilogue_staged<T, true>(p, acc, smem + T2_LDS + wave * 4096, m0 + wm * 128, n0 + wn_ * 64, elane,
-                                          bias_lane))
-                epilogue<T, 8, 4, true>(p, acc, m0 + wm * 128, n0 + wn_ * 64, elane & 15, elane >> 4, bias_lane);
+            char* region = smem + T2_LDS + wave * 4096;
+            const int mb = m0 + wm * 128, nb = n0 + wn_ * 64;
+            if (LNF) {
+                epilogue_staged_f<T, true, true>(p, acc, region, mb, nb, elane, el);   // host: a staged variant exists
+            } else if (!epilogue_staged<T, true>(p, acc, region, mb, nb, elane, el)) {
+                epilogue<T, 8, 4, true>(p, acc, mb, nb, elane & 15, elane >> 4, el);
+            }
         } else if (p.debug == 1) {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
@@ -867,7 +1059,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
         // pipeline every iteration.  Here it only waits for the acknowledgement of the last stores.  Unconditional: the
         // pass cannot tell that !more leaves the loop.
         __builtin_amdgcn_s_waitcnt(0x0F70);
-        bias_lane = next_bias_lane;
+        *el_park = el_next;
         id += G8; m0 = m1; n0 = n1;
     }
     if (wave < 4) T2_BARRIER();   // matches the stagger barrier of waves 4-7
@@ -920,6 +1112,7 @@ int launch(const tdc_gemm_desc* d, hipStream_t st) {
     a.lda = d->lda; a.ldw = d->ldw; a.ldc = d->ldc; a.ldres = d->ldres;
     a.M = d->M; a.N = d->N; a.K = d->K;
     a.out_f32 = d->out_f32; a.res_f32 = d->res_f32; a.act = d->act;
+    a.x16 = d->x16; a.ldx16 = d->ldx16; a.ln_part = d->ln_part; a.ln_stats = d->ln_stats; a.ln_c1 = d->ln_c1;
     { const char* e = getenv("TDC_GEMM_DEBUG"); a.debug = e ? atoi(e) : 0; }
 #ifdef TDC_GEMM_DIAG
     a.stamps = tdc_gemm_diag_stamps;
@@ -938,15 +1131,21 @@ int launch(const tdc_gemm_desc* d, hipStream_t st) {
         }
         // persistent form: more tiles than CUs, identity a_map, K >= 128, in-tile byte offsets fit 32 bits
         const int G = persistent_grid();
-        if (G > 0 && a.tiles_m * a.tiles_n > G && d->a_map.seg == 0 && d->K >= 128 &&
+        // (the LayerNorm-fold instance only carries the LDS-staged epilogues)
+        const bool fold_ok = !d->ln_stats || (!(d->ldc & 7) && !((uintptr_t)d->C & 15) &&
+                                              d->N % (d->act == TDC_ACT_SWIGLU ? 16 : 8) == 0);
+        if (G > 0 && a.tiles_m * a.tiles_n > G && d->a_map.seg == 0 && d->K >= 128 && fold_ok &&
             256ll * d->lda * 2 < (1ll << 31) && 256ll * d->ldw * 2 < (1ll << 31)) {
             static bool attr256p = false;
             if (!attr256p) {
-                HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm256p_kernel<T>,
+                HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm256p_kernel<T, false>,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, T2P_LDS));
+                HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm256p_kernel<T, true>,
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, T2P_LDS));
                 attr256p = true;
             }
-            hipLaunchKernelGGL(gemm256p_kernel<T>, dim3(G), dim3(512), T2P_LDS, st, a);
+            if (d->ln_stats) hipLaunchKernelGGL((gemm256p_kernel<T, true>), dim3(G), dim3(512), T2P_LDS, st, a);
+            else hipLaunchKernelGGL((gemm256p_kernel<T, false>), dim3(G), dim3(512), T2P_LDS, st, a);
             return (int)hipGetLastError();
         }
         hipLaunchKernelGGL(gemm256_kernel<T>, dim3(a.tiles_m * a.tiles_n), dim3(512), T2_LDS, st, a);
@@ -975,6 +1174,17 @@ extern "C" int tdc_gemm(const tdc_gemm_desc* d, void* stream) {
     if ((d->lda % 8) || (d->ldw % 8) || (d->ldc % 4) || (d->res && (d->ldres % 4)) || d->ldw < d->K) return TDC_E_BADARG;
     /* lda < K is legal: rows of A may overlap (sliding-window views, e.g. the BEATs conv positional embedding) */
     if (d->act != TDC_ACT_NONE && d->res) return TDC_E_BADARG;  /* activation epilogues take no residual */
+    if (d->x16) {   /* LayerNorm fusion, producer: fp32 residual-stream update with identity row maps, whole 64-column slots */
+        if (!d->ln_part || !d->out_f32 || !d->res || !d->res_f32 || d->act != TDC_ACT_NONE || d->N % 64 != 0 ||
+            d->c_map.seg != 0 || d->r_map.seg != 0 || d->ldx16 % 4 != 0 || d->ldx16 < d->N || ((uintptr_t)d->x16 & 7) ||
+            ((uintptr_t)d->ln_part & 7))
+            return TDC_E_BADARG;
+    }
+    if (d->ln_stats) {   /* consumer: 16-bit output without residual, row statistics indexed by the A / C row */
+        if (!d->ln_c1 || d->out_f32 || d->res || d->a_map.seg != 0 || ((uintptr_t)d->ln_stats & 7) ||
+            ((uintptr_t)d->ln_c1 & 15))
+            return TDC_E_BADARG;
+    }
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == TDC_F16) return launch<f16>(d, st);
     if (d->dtype == TDC_BF16) return launch<bf16>(d, st);

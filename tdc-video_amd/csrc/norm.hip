@@ -244,3 +244,35 @@ extern "C" int tdc_qformer_embed(const tdc_qembed_desc* d, void* stream) {
 #undef QE
     return (int)hipGetLastError();
 }
+
+// ---- LayerNorm fusion: row statistics from the per-slot partials of the producer GEMM ----------------------------------
+// (tdc_gemm with x16 / ln_part).  One thread per row; slots of 64 columns are combined in index order (Chan):
+// mean = sum(mean_s) / S, M2 = sum(M2_s) + 64 * sum((mean_s - mean)^2); rstd as in ln_kernel.
+namespace {
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ part, int slots, int rows, float eps,
+                                                          float* __restrict__ stats) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float2* p = (const float2*)part + r;          // slot-major: part[s][rows][2] -> coalesced across the rows
+    float sm = 0.f;
+    for (int s = 0; s < slots; ++s) sm += p[(long long)s * rows].x;
+    const float mean = sm / (float)slots;
+    float m2 = 0.f, dv = 0.f;
+    for (int s = 0; s < slots; ++s) {
+        const float2 v = p[(long long)s * rows];
+        const float d = v.x - mean;
+        m2 += v.y;
+        dv = __builtin_fmaf(d, d, dv);
+    }
+    const float q = m2 + 64.0f * dv;
+    *(float2*)(stats + 2 * (long long)r) = make_float2(mean, rsqrtf(q / (float)(slots * 64) + eps));
+}
+}  // namespace
+
+extern "C" int tdc_ln_finalize(const float* ln_part, int slots, int rows, float eps, float* stats, void* stream) {
+    if (!ln_part || !stats || slots <= 0 || rows <= 0 || ((uintptr_t)ln_part & 7) || ((uintptr_t)stats & 7))
+        return TDC_E_BADARG;
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, ln_part, slots,
+                       rows, eps, stats);
+    return (int)hipGetLastError();
+}

@@ -19,7 +19,9 @@ class GemmDesc(C.Structure):
                 ("C", C.c_void_p), ("ldc", C.c_int), ("bias", C.c_void_p), ("res", C.c_void_p), ("ldres", C.c_int),
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
                 ("dtype", C.c_int), ("out_f32", C.c_int), ("res_f32", C.c_int), ("act", C.c_int),
-                ("a_map", RowMap), ("c_map", RowMap), ("r_map", RowMap)]
+                ("a_map", RowMap), ("c_map", RowMap), ("r_map", RowMap),
+                ("x16", C.c_void_p), ("ldx16", C.c_int), ("ln_part", C.c_void_p),
+                ("ln_stats", C.c_void_p), ("ln_c1", C.c_void_p)]
 
 
 class LnDesc(C.Structure):
@@ -66,7 +68,8 @@ class Lin(C.Structure):
 
 class VitLayer(C.Structure):
     _fields_ = [("ln1_g", C.c_void_p), ("ln1_b", C.c_void_p), ("ln2_g", C.c_void_p), ("ln2_b", C.c_void_p),
-                ("qkv", Lin), ("out", Lin), ("fc1", Lin), ("fc2", Lin)]
+                ("qkv", Lin), ("out", Lin), ("fc1", Lin), ("fc2", Lin),
+                ("qkv_c1", C.c_void_p), ("fc1_c1", C.c_void_p)]
 
 
 class VitModel(C.Structure):
@@ -74,7 +77,7 @@ class VitModel(C.Structure):
                 ("n_layers", C.c_int), ("patch", C.c_int), ("has_cls", C.c_int), ("act", C.c_int),
                 ("eps", C.c_float), ("patch_lin", Lin), ("pos", C.c_void_p), ("ldpos", C.c_int),
                 ("cls_row", C.c_void_p), ("lnf_g", C.c_void_p), ("lnf_b", C.c_void_p),
-                ("layers_host", C.POINTER(VitLayer))]
+                ("layers_host", C.POINTER(VitLayer)), ("fused", C.c_int)]
 
 
 class QformerLayer(C.Structure):
@@ -95,6 +98,7 @@ class QformerModel(C.Structure):
 # name -> (restype, argtypes); every symbol include/tdc_hip.h declares
 SIGNATURES = {
     "tdc_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
+    "tdc_ln_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "tdc_layernorm": (C.c_int, [C.POINTER(LnDesc), C.c_void_p]),
     "tdc_attention": (C.c_int, [C.POINTER(AttnDesc), C.c_void_p]),
     "tdc_im2col": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -78,8 +78,10 @@ def _map_max(m, M):
 
 
 def gemm(a, w, bias=None, act=L.ACT_NONE, res=None, out=None, out_f32=False, M=None, a_map=None, c_map=None,
-         r_map=None, out_rows=None):
-    """out[c_map(m)] = act(a[a_map(m)] @ w.T + bias) + res[r_map(m)].  a [Ra, lda], w [N, K] (both 16-bit)."""
+         r_map=None, out_rows=None, x16=None, ln_part=None, ln_stats=None, ln_c1=None):
+    """out[c_map(m)] = act(a[a_map(m)] @ w.T + bias) + res[r_map(m)].  a [Ra, lda], w [N, K] (both 16-bit).
+    LayerNorm fusion (include/tdc_hip.h): x16 / ln_part = producer outputs (16-bit copy of the fp32 result, per-slot
+    (mean, M2) partials [N/64, M, 2]); ln_stats [M, 2] / ln_c1 [N] = consumer inputs (a = raw rows, w = folded weight)."""
     _chk2d(a, "a"); _chk2d(w, "w")
     N, K = w.shape
     assert a.dtype == w.dtype and K % 64 == 0 and a.shape[1] >= K, (a.shape, w.shape)
@@ -110,6 +112,17 @@ def gemm(a, w, bias=None, act=L.ACT_NONE, res=None, out=None, out_f32=False, M=N
     d.M, d.N, d.K = M, N, K
     d.dtype, d.out_f32, d.act = _dt(a), int(out_f32), act
     d.a_map, d.c_map, d.r_map = _map(a_map), _map(c_map), _map(r_map)
+    if x16 is not None:
+        _chk2d(x16, "x16")
+        assert ln_part is not None and out_f32 and res is not None and N % 64 == 0 and c_map is None and r_map is None
+        assert x16.dtype == a.dtype and x16.shape[0] >= M and x16.shape[1] >= N
+        assert ln_part.dtype == torch.float32 and ln_part.is_contiguous() and ln_part.numel() >= M * (N // 64) * 2
+        d.x16, d.ldx16, d.ln_part = x16.data_ptr(), x16.stride(0), ln_part.data_ptr()
+    if ln_stats is not None:
+        assert ln_c1 is not None and not out_f32 and res is None and a_map is None
+        assert ln_stats.dtype == torch.float32 and ln_stats.is_contiguous() and ln_stats.numel() >= 2 * M
+        assert ln_c1.dtype == torch.float32 and ln_c1.is_contiguous() and ln_c1.numel() >= N
+        d.ln_stats, d.ln_c1 = ln_stats.data_ptr(), ln_c1.data_ptr()
     e0 = _prof_begin("gemm")
     L.check(L.load().tdc_gemm(C.byref(d), _stream()), "tdc_gemm")
     if e0 is not None:
@@ -118,6 +131,16 @@ def gemm(a, w, bias=None, act=L.ACT_NONE, res=None, out=None, out_f32=False, M=N
         if "gemm_shapes" in PROFILE:
             PROFILE["gemm_shapes"].append((M, N, K, act, int(res is not None), int(out_f32)))
     return out
+
+
+def ln_finalize(ln_part, slots, rows, eps, stats=None):
+    """per-slot (mean, M2) partials [slots, rows, 2] of a producer GEMM -> stats [rows, 2] = (mean, rstd)."""
+    assert ln_part.dtype == torch.float32 and ln_part.is_contiguous() and ln_part.numel() >= rows * slots * 2
+    if stats is None:
+        stats = torch.empty(rows, 2, device=ln_part.device, dtype=torch.float32)
+    assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.numel() >= 2 * rows
+    L.check(L.load().tdc_ln_finalize(_ptr(ln_part), slots, rows, eps, _ptr(stats), _stream()), "tdc_ln_finalize")
+    return stats
 
 
 def layernorm(x, gamma, beta, eps, cols, dtype, y16=None, y32=None, add=None, add_period=0, add_mode=0,

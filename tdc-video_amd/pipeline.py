@@ -75,7 +75,9 @@ class VideoEncoder:
         layers = (L.VitLayer * len(t.layers))()
         for i, Lr in enumerate(t.layers):
             layers[i] = L.VitLayer(Lr.ln1_g.data_ptr(), Lr.ln1_b.data_ptr(), Lr.ln2_g.data_ptr(), Lr.ln2_b.data_ptr(),
-                                   lin(Lr.qkv), lin(Lr.out), lin(Lr.fc1), lin(Lr.fc2))
+                                   lin(Lr.qkv), lin(Lr.out), lin(Lr.fc1), lin(Lr.fc2),
+                                   Lr.qkv_c1.data_ptr() if Lr.qkv_c1 is not None else None,
+                                   Lr.fc1_c1.data_ptr() if Lr.fc1_c1 is not None else None)
         m = L.VitModel()
         m.dtype = ops._dtcode(self.dtype)
         m.dim, m.heads, m.head_dim, m.n_layers, m.patch, m.has_cls = t.dim, t.heads, t.head_dim, len(t.layers), t.patch, \
@@ -88,6 +90,7 @@ class VideoEncoder:
         fl = t.get("final_ln")
         m.lnf_g, m.lnf_b = (fl[0].data_ptr(), fl[1].data_ptr()) if fl else (None, None)
         m.layers_host = layers
+        m.fused = int(bool(t.fused))
         cache[(gh, gw)] = (m, layers, pos, cls_row)
         return cache[(gh, gw)]
 
@@ -135,16 +138,34 @@ class VideoEncoder:
         mlp_w = t.layers[0].fc2.w.shape[1] if t.layers else 0
         mlp = torch.empty(B * S, mlp_w, device=dev, dtype=dt) if t.layers else None
         scale = t.head_dim ** -0.5
-        for Lr in t.layers:
-            ops.layernorm(x32, Lr.ln1_g, Lr.ln1_b, t.eps, D, dt, y16=h16)
-            ops.gemm(h16, Lr.qkv.w, Lr.qkv.b, out=qkv)
+        # t.fused: the block's LayerNorms are folded into the GEMMs around them - the residual-stream GEMM emits the
+        # 16-bit row copy (into h16) and per-slot statistics, the next GEMM folds (mean, rstd) into its epilogue
+        fused = bool(t.fused)
+        slots = D // 64
+        part = torch.empty(slots, B * S, 2, device=dev, dtype=torch.float32) if fused else None
+        stats = torch.empty(B * S, 2, device=dev, dtype=torch.float32) if fused else None
+        emit = dict(x16=h16, ln_part=part) if fused else {}
+        for li, Lr in enumerate(t.layers):
+            if Lr.qkv_c1 is None:
+                ops.layernorm(x32, Lr.ln1_g, Lr.ln1_b, t.eps, D, dt, y16=h16)
+                ops.gemm(h16, Lr.qkv.w, Lr.qkv.b, out=qkv)
+            else:
+                ops.gemm(h16, Lr.qkv.w, Lr.qkv.b, out=qkv, ln_stats=stats, ln_c1=Lr.qkv_c1)
             ld = qkv.stride(0)
             ops.attention(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], attn, B, t.heads, t.head_dim, S, S, scale,
                           S * ld, S * ld, S * ld, S * attn.stride(0))
-            ops.gemm(attn, Lr.out.w, Lr.out.b, res=x32, out=x32, out_f32=True)
-            ops.layernorm(x32, Lr.ln2_g, Lr.ln2_b, t.eps, D, dt, y16=h16)
-            ops.gemm(h16, Lr.fc1.w, Lr.fc1.b, act=act, out=mlp)
-            ops.gemm(mlp, Lr.fc2.w, Lr.fc2.b, res=x32, out=x32, out_f32=True)
+            ops.gemm(attn, Lr.out.w, Lr.out.b, res=x32, out=x32, out_f32=True, **emit)
+            if fused:
+                ops.ln_finalize(part, slots, B * S, t.eps, stats)
+                ops.gemm(h16, Lr.fc1.w, Lr.fc1.b, act=act, out=mlp, ln_stats=stats, ln_c1=Lr.fc1_c1)
+            else:
+                ops.layernorm(x32, Lr.ln2_g, Lr.ln2_b, t.eps, D, dt, y16=h16)
+                ops.gemm(h16, Lr.fc1.w, Lr.fc1.b, act=act, out=mlp)
+            if fused and li + 1 < len(t.layers):
+                ops.gemm(mlp, Lr.fc2.w, Lr.fc2.b, res=x32, out=x32, out_f32=True, **emit)
+                ops.ln_finalize(part, slots, B * S, t.eps, stats)
+            else:
+                ops.gemm(mlp, Lr.fc2.w, Lr.fc2.b, res=x32, out=x32, out_f32=True)
         src = x32
         if t.get("final_ln"):
             ops.layernorm(x32, t.final_ln[0], t.final_ln[1], t.eps, D, dt, y16=h16)

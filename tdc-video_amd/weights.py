@@ -73,6 +73,22 @@ def stack_lins(parts, dtype, dev, k_pad=None, n_pad=None):
     return make_lin(Wc, bc, dtype, dev, k_pad=k_pad, n_pad=n_pad)
 
 
+def fold_c1(lin):
+    """Row sums of a prepared (16-bit, padded) weight, fp32: the `ln_c1` operand of a LayerNorm-folded GEMM
+    (include/tdc_hip.h, tdc_gemm_desc).  Summed from the ROUNDED weight so that mean * c1 cancels exactly what the MFMAs
+    accumulate."""
+    return lin.w.float().sum(1).contiguous()
+
+
+def ln_fusion_enabled(dim):
+    """TDC_LN_FUSE=1: the towers fold their pre-LayerNorms into the neighbouring GEMMs (widths that are a whole number
+    of 64-column slots).  Off by default: measured neutral on MI355X (+0.4 % frames/s) - the fold
+    moves the LayerNorm's bytes (an HBM-bound kernel at 5.3 TB/s) into the GEMM epilogue, which is bound by the
+    16 B/clk store path of a CU; it pays once that drain is overlapped with MFMA work."""
+    import os
+    return dim % 64 == 0 and os.environ.get("TDC_LN_FUSE", "0") == "1"
+
+
 def vec32(v, dev, n_pad=None, fill=0.0):
     v = v.detach().to(torch.float32).flatten()
     n_pad = pad64(v.numel()) if n_pad is None else n_pad
@@ -127,7 +143,7 @@ def prep_siglip(sd, heads, dtype, dev, patch=14, eps=1e-6):
     Wp = sd["embeddings.patch_embedding.weight"]
     D = Wp.shape[0]
     t = Namespace(kind="siglip", dim=D, heads=heads, head_dim=D // heads, patch=patch, eps=eps, has_cls=0,
-                  act="gelu_tanh", final_ln=None)
+                  act="gelu_tanh", final_ln=None, fused=ln_fusion_enabled(D))
     t.patch_lin = make_lin(Wp.reshape(D, -1), sd["embeddings.patch_embedding.bias"], dtype, dev)
     t.pos_table = sd["embeddings.position_embedding.weight"].detach().float().cpu()  # [P, D]
     t.layers = []
@@ -136,11 +152,17 @@ def prep_siglip(sd, heads, dtype, dev, patch=14, eps=1e-6):
         p = "encoder.layers.%d." % i
         Lr = Namespace()
         Lr.ln1_g, Lr.ln1_b = vec32(sd[p + "layer_norm1.weight"], dev), vec32(sd[p + "layer_norm1.bias"], dev)
-        Lr.qkv = stack_lins([(sd[p + "self_attn.%s_proj.weight" % n], sd[p + "self_attn.%s_proj.bias" % n], None)
+        # LayerNorm fusion (t.fused): LN1 of layers >= 1 and every LN2 are folded into the consuming GEMM: weight
+        # W diag(gamma), bias beta W^T + b, c1 = row sums; layer 0's LN1 follows the patch embedding and stays a kernel
+        f1 = dict(col_scale=sd[p + "layer_norm1.weight"], col_shift=sd[p + "layer_norm1.bias"]) if t.fused and i > 0 else None
+        f2 = dict(col_scale=sd[p + "layer_norm2.weight"], col_shift=sd[p + "layer_norm2.bias"]) if t.fused else {}
+        Lr.qkv = stack_lins([(sd[p + "self_attn.%s_proj.weight" % n], sd[p + "self_attn.%s_proj.bias" % n], f1)
                              for n in "qkv"], dtype, dev)
+        Lr.qkv_c1 = fold_c1(Lr.qkv) if f1 else None
         Lr.out = make_lin(sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"], dtype, dev)
         Lr.ln2_g, Lr.ln2_b = vec32(sd[p + "layer_norm2.weight"], dev), vec32(sd[p + "layer_norm2.bias"], dev)
-        Lr.fc1 = make_lin(sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"], dtype, dev)
+        Lr.fc1 = make_lin(sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"], dtype, dev, **f2)
+        Lr.fc1_c1 = fold_c1(Lr.fc1) if f2 else None
         Lr.fc2 = make_lin(sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"], dtype, dev)
         t.layers.append(Lr)
         i += 1
@@ -153,7 +175,7 @@ def prep_dino(sd, heads, dtype, dev, patch=14, eps=1e-6):
     Wp = sd["embeddings.patch_embeddings.projection.weight"]
     D = Wp.shape[0]
     t = Namespace(kind="dino", dim=D, heads=heads, head_dim=D // heads, patch=patch, eps=eps, has_cls=1,
-                  act="swiglu")
+                  act="swiglu", fused=ln_fusion_enabled(D))
     t.patch_lin = make_lin(Wp.reshape(D, -1), sd["embeddings.patch_embeddings.projection.bias"], dtype, dev)
     t.pos_table = sd["embeddings.position_embeddings"].detach().float().cpu()[0]  # [1+n*n, D]
     t.cls = sd["embeddings.cls_token"].detach().float().cpu().flatten()
@@ -163,8 +185,11 @@ def prep_dino(sd, heads, dtype, dev, patch=14, eps=1e-6):
         p = "encoder.layer.%d." % i
         Lr = Namespace()
         Lr.ln1_g, Lr.ln1_b = vec32(sd[p + "norm1.weight"], dev), vec32(sd[p + "norm1.bias"], dev)
+        f1 = dict(col_scale=sd[p + "norm1.weight"], col_shift=sd[p + "norm1.bias"]) if t.fused and i > 0 else None
+        f2 = dict(col_scale=sd[p + "norm2.weight"], col_shift=sd[p + "norm2.bias"]) if t.fused else {}
         Lr.qkv = stack_lins([(sd[p + "attention.attention.%s.weight" % n], sd[p + "attention.attention.%s.bias" % n],
-                              None) for n in ("query", "key", "value")], dtype, dev)
+                              f1) for n in ("query", "key", "value")], dtype, dev)
+        Lr.qkv_c1 = fold_c1(Lr.qkv) if f1 else None
         Lr.out = make_lin(sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"], dtype, dev,
                           row_scale=sd[p + "layer_scale1.lambda1"])
         Lr.ln2_g, Lr.ln2_b = vec32(sd[p + "norm2.weight"], dev), vec32(sd[p + "norm2.bias"], dev)
@@ -176,16 +201,17 @@ def prep_dino(sd, heads, dtype, dev, patch=14, eps=1e-6):
             bi = torch.zeros(2 * hp, device=Win.device)
             Wi[0:2 * hid:2], Wi[1:2 * hid:2] = Win[:hid], Win[hid:]
             bi[0:2 * hid:2], bi[1:2 * hid:2] = bin_[:hid], bin_[hid:]
-            Lr.fc1 = make_lin(Wi, bi, dtype, dev, n_pad=2 * hp)
+            Lr.fc1 = make_lin(Wi, bi, dtype, dev, n_pad=2 * hp, **f2)
             Lr.fc1.w._real_nk = (2 * hid, Win.shape[1])
             Lr.fc2 = make_lin(sd[p + "mlp.weights_out.weight"], sd[p + "mlp.weights_out.bias"], dtype, dev,
                               row_scale=sd[p + "layer_scale2.lambda1"])
             t.act = "swiglu"
         else:
-            Lr.fc1 = make_lin(sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"], dtype, dev)
+            Lr.fc1 = make_lin(sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"], dtype, dev, **f2)
             Lr.fc2 = make_lin(sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"], dtype, dev,
                               row_scale=sd[p + "layer_scale2.lambda1"])
             t.act = "gelu_erf"
+        Lr.fc1_c1 = fold_c1(Lr.fc1) if f2 else None
         t.layers.append(Lr)
         i += 1
     t.final_ln = (vec32(sd["layernorm.weight"], dev), vec32(sd["layernorm.bias"], dev))

@@ -142,8 +142,9 @@ def full_sd():
     return {k: v.float().cpu() for k, v in sd.items()}, bench.model_cfg(H, K, T), H, K
 
 
+@pytest.mark.parametrize("fuse", ["0", "1"])
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 8e-3), (torch.bfloat16, 6e-2)])
-def test_fullsize_towers_vs_oracle(full_sd, dtype, tol):
+def test_fullsize_towers_vs_oracle(full_sd, dtype, tol, fuse, monkeypatch):
     """SigLIP-so400m (27 x 1152, d_head 72) and DINOv2-giant (40 x 1536, SwiGLU, LayerScale) at full depth and width:
     2 frames, HIP vs the fp32 oracle.  Tolerances are relative to max|ref| of the tower output: the raw residual
     stream of a random-init 40-layer ViT is carried through 80 16-bit GEMM inputs (bf16: 8 mantissa bits)."""
@@ -151,6 +152,7 @@ def test_fullsize_towers_vs_oracle(full_sd, dtype, tol):
     from tdc_video_amd.pipeline import VideoEncoder
     orc = _oracle()
     sd, cfg, H, K = full_sd
+    monkeypatch.setenv("TDC_LN_FUSE", fuse)     # "1": pre-LayerNorms folded into the neighbouring GEMMs
     enc = VideoEncoder(sd, cfg, dtype=dtype, device="cuda:0", tower_batch=2)
     g = torch.Generator().manual_seed(5)
     xs = torch.rand(2, 3, 384, 384, generator=g) * 2 - 1
@@ -163,7 +165,7 @@ def test_fullsize_towers_vs_oracle(full_sd, dtype, tol):
     got_s = enc.tower("siglip", xs.cuda())[:, :1152].reshape(2, 576, 1152)
     got_d = enc.tower("dino", xd.cuda())[:, :1536].reshape(2, 576, 1536)
     es, ed = _rel(got_s, ref_s), _rel(got_d, ref_d)
-    print("full-size tower rel err %s: siglip %.3e dino %.3e" % (dtype, es, ed))
+    print("full-size tower rel err %s fuse=%s: siglip %.3e dino %.3e" % (dtype, fuse, es, ed))
     assert es < tol and ed < tol, (es, ed)
 
 
@@ -244,3 +246,29 @@ def test_fullsize_video_plus_audio_token_accounting(full):
         enc.cfg["audio_input"], enc.c.audio_proj, enc.beats = old
         if old[0] is None:
             enc.cfg.pop("audio_input", None)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 8e-3), (torch.bfloat16, 6e-2)])
+def test_fullsize_ln_fusion_matches_layernorm_kernel(full_sd, dtype, tol, monkeypatch):
+    """TDC_LN_FUSE=1 (pre-LayerNorms folded into the neighbouring GEMMs: 16-bit row copy + per-slot statistics out of the
+    residual-stream GEMM, (mean, rstd) folded into the next GEMM's epilogue) against the LayerNorm-kernel path, both
+    towers at full depth / width; and the fused path is batch invariant bit for bit like everything else."""
+    import bench
+    import tdc_video_amd  # noqa: F401
+    from tdc_video_amd.pipeline import VideoEncoder
+    sd, cfg, _, _ = full_sd
+    vs = bench.synth_video(0, 3, 384, "cuda:0", dtype)
+    vd = bench.synth_video(0, 3, 378, "cuda:0", dtype, seed=4321)
+    outs = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("TDC_LN_FUSE", fuse)
+        enc = VideoEncoder(sd, cfg, dtype=dtype, device="cuda:0", tower_batch=3)
+        assert all(bool(t.fused) == (fuse == "1") for t in enc.towers.values())
+        outs[fuse] = (enc.tower("siglip", vs).float(), enc.tower("dino", vd).float())
+        if fuse == "1":
+            enc.tower_batch = 2
+            assert torch.equal(enc.tower("dino", vd).float(), outs[fuse][1])
+        del enc
+        torch.cuda.empty_cache()
+    for a, b in zip(outs["0"], outs["1"]):
+        assert ((a - b).abs().max() / a.abs().max()).item() < tol

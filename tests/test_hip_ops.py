@@ -112,6 +112,61 @@ def test_gemm_persistent(ops, dtype, N):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M", [300, 8192, 80 * 256 - 19])
+def test_gemm_layernorm_fusion(ops, dtype, M):
+    """LayerNorm fused into the GEMMs around it: the producer (fp32 residual update) also emits the 16-bit row copy and
+    per-slot (mean, M2) partials, tdc_ln_finalize turns them into (mean, rstd), the consumer folds them into its
+    epilogue.  The three M exercise the 128x128, the 256x256 and the persistent kernel; every output of the small launch
+    of a row range must be BITWISE equal to the same rows of the large launch (kernel-independent rows)."""
+    from tdc_video_amd import lib as L
+    g = torch.Generator(device="cuda").manual_seed(11)
+    D, K, N2, eps = 1152, 256, 1216, 1e-6
+    a = torch.randn(M, K, device="cuda", generator=g).to(dtype)
+    w = (torch.randn(D, K, device="cuda", generator=g) / math.sqrt(K)).to(dtype)
+    b = torch.randn(D, device="cuda", generator=g)
+    x0 = torch.randn(M, D, device="cuda", generator=g) * 2 + 0.7        # residual stream with a non-zero mean
+
+    def producer(a_, x_):
+        x = x_.clone()
+        x16 = torch.empty(x.shape[0], D, device="cuda", dtype=dtype)
+        part = torch.empty(D // 64, x.shape[0], 2, device="cuda", dtype=torch.float32)   # slot-major
+        ops.gemm(a_, w, b, res=x, out=x, out_f32=True, x16=x16, ln_part=part)
+        return x, x16, part, ops.ln_finalize(part, D // 64, x.shape[0], eps)
+
+    x, x16, part, stats = producer(a, x0)
+    ref = a.float() @ w.float().t() + b + x0
+    assert relerr(x, ref) < tol(dtype)
+    assert torch.equal(x16, x.to(dtype))
+    mean = x.mean(1)
+    rstd = (x.var(1, unbiased=False) + eps).rsqrt()
+    assert (stats[:, 0] - mean).abs().max().item() < 1e-5 * x.abs().max().item()
+    assert ((stats[:, 1] - rstd).abs() / rstd).max().item() < 1e-5
+    # consumer: LN(x) W2^T + b2 through the folded weight
+    gamma = 1.0 + 0.1 * torch.randn(D, device="cuda", generator=g)
+    beta = 0.1 * torch.randn(D, device="cuda", generator=g)
+    w2 = torch.randn(N2, D, device="cuda", generator=g) / math.sqrt(D)
+    b2 = torch.randn(N2, device="cuda", generator=g)
+    wf = (w2 * gamma[None, :]).to(dtype)
+    c1 = wf.float().sum(1).contiguous()
+    c2 = (w2 @ beta + b2).contiguous()
+    lin = F.layer_norm(x, (D,), gamma, beta, eps) @ w2.t() + b2
+    outs = {}
+    for name, act, want in (("none", L.ACT_NONE, lin), ("tanh", L.ACT_GELU_TANH, F.gelu(lin, approximate="tanh")),
+                            ("erf", L.ACT_GELU_ERF, F.gelu(lin)),
+                            ("swiglu", L.ACT_SWIGLU, F.silu(lin[:, 0::2]) * lin[:, 1::2])):
+        outs[name] = ops.gemm(x16, wf, c2, act=act, ln_stats=stats, ln_c1=c1)
+        assert relerr(outs[name], want) < 2 * tol(dtype), name
+    if M > 300:
+        for lo in (0, M // 2 + 3, M - 300):
+            xs, x16s, parts, statss = producer(a[lo:lo + 300].contiguous(), x0[lo:lo + 300])
+            assert torch.equal(xs, x[lo:lo + 300]) and torch.equal(x16s, x16[lo:lo + 300])
+            assert torch.equal(parts, part[:, lo:lo + 300]) and torch.equal(statss, stats[lo:lo + 300])
+            for name, act in (("none", L.ACT_NONE), ("tanh", L.ACT_GELU_TANH), ("swiglu", L.ACT_SWIGLU)):
+                sub = ops.gemm(x16s, wf, c2, act=act, ln_stats=statss, ln_c1=c1)
+                assert torch.equal(sub, outs[name][lo:lo + 300]), name
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_gemm_row_maps(ops, dtype):
     g = torch.Generator(device="cuda").manual_seed(2)
     F_, S, Kq, D, N = 5, 11, 4, 128, 64

@@ -107,10 +107,13 @@ def _rand_tower_sd(kind, D, heads, mlp, layers, grid_in, g, std=0.05):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("kind,D,heads,mlp,px", [("siglip", 144, 2, 272, 126), ("dino", 128, 2, 344, 126),
-                                                  ("siglip", 288, 4, 560, 112)])
-def test_towers_natural_scale(kind, D, heads, mlp, px, dtype):
-    """Real head dims (72: the padded-to-96 MFMA path, 64) at trained-model-like scales, HIP vs oracle."""
+@pytest.mark.parametrize("kind,D,heads,mlp,px,fuse", [("siglip", 144, 2, 272, 126, "0"), ("dino", 128, 2, 344, 126, "0"),
+                                                       ("siglip", 288, 4, 560, 112, "0"), ("dino", 128, 2, 344, 126, "1"),
+                                                       ("siglip", 192, 3, 400, 126, "1")])
+def test_towers_natural_scale(kind, D, heads, mlp, px, fuse, dtype, monkeypatch):
+    """Real head dims (72: the padded-to-96 MFMA path, 64) at trained-model-like scales, HIP vs oracle; fuse = "1": the
+    pre-LayerNorms folded into the neighbouring GEMMs (TDC_LN_FUSE, widths that are multiples of 64)."""
+    monkeypatch.setenv("TDC_LN_FUSE", fuse)
     import tdc_video_amd  # noqa: F401
     from tdc_video_amd import weights as Wt
     from tdc_video_amd.pipeline import VideoEncoder
@@ -418,9 +421,12 @@ def test_raw_waveform_audio_through_beats_vs_oracle():
     assert rel(vis, ref) < stage_tol(torch.float16)
 
 
+@pytest.mark.parametrize("fuse", ["0", "1"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_native_tower_composite_equals_kernel_sequence(dtype):
-    """tdc_vit_fwd (C++ composite) launches the same kernels as the per-kernel Python sequence: bit-identical output."""
+def test_native_tower_composite_equals_kernel_sequence(dtype, fuse, monkeypatch):
+    """tdc_vit_fwd (C++ composite) launches the same kernels as the per-kernel Python sequence: bit-identical output
+    (fuse = "1": with the LayerNorm fusion; the DINO fixture is 64 wide, the 48-wide SigLIP one stays unfused)."""
+    monkeypatch.setenv("TDC_LN_FUSE", fuse)
     import tdc_video_amd  # noqa: F401
     from tdc_video_amd import weights as Wt
     from tdc_video_amd.pipeline import VideoEncoder
