@@ -128,6 +128,9 @@ int tdc_adaptive_pool_tokens(const void* x, int N, int frame_rows, int ld, void*
 typedef struct { const void* base[4]; int ld[4]; } tdc_gather_tables;
 int tdc_gather_rows(const tdc_gather_tables* t, const int* src, void* out, int ldo, int n, int cols, int dtype,
                     void* stream);
+/* every row of out [rows, ld] (16-bit, ld % 8 == 0) := row[0 .. ld) (the SVA queries start as `vision_query` on every
+ * window of every frame, cambrian_arch.py:1018-1023) */
+int tdc_fill_rows(const void* row, void* out, int ld, int rows, void* stream);
 /* rows of x [rows, ld] 16-bit scaled to unit L2 norm over `cols` (F.normalize, eps 1e-12; cambrian_arch.py:1664) */
 int tdc_l2_normalize(void* x, int ld, int rows, int cols, int dtype, void* stream);
 /* SVA core (tdc/vision_sampler.py:215-291): per query (frame t, window (i,j)) attend over the 2x2 windows of
@@ -216,6 +219,36 @@ size_t tdc_qformer_workspace_bytes(const tdc_qformer_model* m, int F, int K, int
 int tdc_qformer_fwd(const tdc_qformer_model* m, const void* enc, int ldenc, int F, int Nenc, const void* query, int ldq,
                     const int* qsrc, const int* ids, int Lt, int K, void* out, int ldo, void* workspace,
                     size_t workspace_bytes, void* stream);
+
+/* ---- composite: the connector (a6-a9) -------------------------------------------------------------------------------
+ * Replaces mm_projector_aux_{0,1} + global context (tdc/cambrian_arch.py:80-90,1002-1013), the window gather + masks and
+ * the 3-layer `vision_sampler_0` (cambrian_arch.py:601-695,1018-1053; tdc/vision_sampler.py:170-401,519-566) and
+ * `mm_projector` (cambrian_arch.py:65-69,1149-1150) for T frames: the two towers' tokens sig [T*P, ld_s] / dino
+ * [T*P, ld_d] (16-bit, P = (side*r)^2 tokens per frame) -> out [T*side*side, ldo] 16-bit in the LLM width H.
+ * mask [T*side*side, 2*r*r] uint8 is the reference's window-validity mask (host geometry: tdc-video_amd/segment.py).
+ * Per SVA layer: proj_context once per frame, proj_in split into its query / context column blocks (the context half is a
+ * per-frame bias), k|v LayerNorm affines folded into ONE [P-token, 2C] GEMM per tower with the position embedding added
+ * inside the LayerNorm launch, tdc_sva_attention, o_proj + residual, LayerNorm, proj_out MLP + residual. */
+typedef struct { tdc_lin fc1, fc2; const float *ln_g, *ln_b; } tdc_aux_proj;
+typedef struct {
+    tdc_lin proj_context, proj_in_c, proj_in_q;
+    const float* pos[2]; int ldpos;                  /* pos_embed_{0,1} [r*r, pad64(C)] fp32 */
+    tdc_lin kv[2];                                   /* (K | V) projection of tower i, LayerNorm affines folded */
+    const float *q_ln_g, *q_ln_b; tdc_lin q_proj, o_proj;
+    const float *norm_g, *norm_b; tdc_lin out1, out2;
+} tdc_sva_layer;
+typedef struct {
+    int dtype, C, side, r, heads, n_layers;
+    tdc_aux_proj aux[2];
+    const void* vision_query;                        /* [pad64(C)] 16-bit, pad columns zero */
+    const float *ones_C, *zeros_C;                   /* [pad64(C)] (the un-affine LayerNorm of the k/v inputs) */
+    const tdc_sva_layer* layers_host;
+    tdc_lin mm1, mm2;                                /* mm_projector: Linear(C, H) + GELU, Linear(H, H) */
+} tdc_connector_model;
+size_t tdc_connector_workspace_bytes(const tdc_connector_model* m, int T);
+int tdc_connector_fwd(const tdc_connector_model* m, const void* sig, int ld_s, const void* dino, int ld_d, int T,
+                      const unsigned char* mask, void* out, int ldo, void* workspace, size_t workspace_bytes,
+                      void* stream);
 
 /* ---- frame pre-processing on the device -----------------------------------------------------------
  * `process_images` for ONE tower (tdc/mm_datautils.py:270-314): frames uint8 [T, H, W, 3] (RGB, as decord / numpy give

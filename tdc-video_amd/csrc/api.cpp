@@ -296,3 +296,110 @@ extern "C" int tdc_vit_fwd(const tdc_vit_model* m, const void* px, int px_f32, i
     }
     return tdc_resample_tokens(src, src_f32, Dp, m->has_cls, g, out, ldo, out_grid, idx0, idx1, frac, B, D, dt, stream);
 }
+
+// ---- connector (a6-a9) -------------------------------------------------------------------------------------------------
+namespace {
+struct ConnWs {
+    size_t h, y32, aux[2], ctx, cproj, cin, q16[2], qin, xn, kv[2], qn, qs, att, q2, mh, total;
+};
+
+ConnWs conn_layout(const tdc_connector_model* m, int T) {
+    const size_t Cp = pad64i(m->C), P = (size_t)(m->side * m->r) * (m->side * m->r), nq = (size_t)m->side * m->side;
+    const size_t rows = (size_t)T * P, qrows = (size_t)T * nq, Hp = m->mm1.n;
+    ConnWs w;
+    size_t off = 0;
+    w.h = off;       off += al256(rows * Cp * 2);             // aux fc1 output
+    w.y32 = off;     off += al256(rows * Cp * 4);             // aux fc2 output (fp32, LayerNorm input)
+    for (int i = 0; i < 2; ++i) { w.aux[i] = off; off += al256(rows * Cp * 2); }
+    w.ctx = off;     off += al256((size_t)T * Cp * 2);
+    w.cproj = off;   off += al256((size_t)T * Cp * 2);
+    w.cin = off;     off += al256((size_t)T * Cp * 4);
+    for (int i = 0; i < 2; ++i) { w.q16[i] = off; off += al256(qrows * Cp * 2); }
+    w.qin = off;     off += al256(qrows * Cp * 4);
+    w.xn = off;      off += al256(rows * Cp * 2);
+    for (int i = 0; i < 2; ++i) { w.kv[i] = off; off += al256(rows * 2 * Cp * 2); }
+    w.qn = off;      off += al256(qrows * Cp * 2);
+    w.qs = off;      off += al256(qrows * Cp * 2);
+    w.att = off;     off += al256(qrows * Cp * 2);
+    w.q2 = off;      off += al256(qrows * Cp * 4);
+    w.mh = off;      off += al256(qrows * (Hp > Cp ? Hp : Cp) * 2);   // proj_out hidden / mm_projector hidden
+    w.total = off;
+    return w;
+}
+
+int ln16(const float* x, int ldx, void* y16, int ldy, const float* g, const float* b, float eps, int rows, int cols,
+         int dtype, void* st) {
+    return layernorm(x, ldx, y16, ldy, g, b, eps, rows, cols, dtype, st);
+}
+}  // namespace
+
+extern "C" size_t tdc_connector_workspace_bytes(const tdc_connector_model* m, int T) {
+    if (!m || T <= 0 || !m->layers_host) return 0;
+    return conn_layout(m, T).total;
+}
+
+extern "C" int tdc_connector_fwd(const tdc_connector_model* m, const void* sig, int ld_s, const void* dino, int ld_d,
+                                 int T, const unsigned char* mask, void* out, int ldo, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    if (!m || !sig || !dino || !mask || !out || !workspace || T <= 0 || m->n_layers <= 0) return TDC_E_BADARG;
+    const ConnWs w = conn_layout(m, T);
+    if (workspace_bytes < w.total || ((uintptr_t)workspace & 255)) return TDC_E_WORKSPACE;
+    char* ws = (char*)workspace;
+    const int C = m->C, Cp = pad64i(C), dt = m->dtype, side = m->side, r = m->r;
+    const int P = side * r * side * r, nq = side * side, rows = T * P, qrows = T * nq;
+    const tdc_rowmap ident = {0, 0, 0, 0};
+    hipStream_t st = (hipStream_t)stream;
+    // a6: mm_projector_aux_i = Linear + GELU(erf), Linear, LayerNorm(1e-5); global context = mean over the tokens of aux_0
+    const void* feats[2] = {sig, dino};
+    const int lds[2] = {ld_s, ld_d};
+    for (int i = 0; i < 2; ++i) {
+        const tdc_aux_proj& a = m->aux[i];
+        RET_IF(gemm(feats[i], lds[i], a.fc1, ws + w.h, Cp, rows, dt, TDC_ACT_GELU_ERF, 0, nullptr, 0, 0, ident, ident, stream));
+        RET_IF(gemm(ws + w.h, Cp, a.fc2, ws + w.y32, Cp, rows, dt, TDC_ACT_NONE, 1, nullptr, 0, 0, ident, ident, stream));
+        RET_IF(ln16((const float*)(ws + w.y32), Cp, ws + w.aux[i], Cp, a.ln_g, a.ln_b, 1e-5f, rows, C, dt, stream));
+    }
+    RET_IF(tdc_token_mean(ws + w.aux[0], P, Cp, ws + w.ctx, T, dt, stream));
+    // queries start as vision_query broadcast to every window of every frame (cambrian_arch.py:1018-1023)
+    RET_IF(tdc_fill_rows(m->vision_query, ws + w.q16[0], Cp, qrows, stream));
+    int cur = 0;
+    for (int l = 0; l < m->n_layers; ++l) {
+        const tdc_sva_layer& L = m->layers_host[l];
+        char* q16 = ws + w.q16[cur];
+        char* q16n = ws + w.q16[cur ^ 1];
+        RET_IF(gemm(ws + w.ctx, Cp, L.proj_context, ws + w.cproj, Cp, T, dt, TDC_ACT_NONE, 0, nullptr, 0, 0, ident, ident, stream));
+        RET_IF(gemm(ws + w.cproj, Cp, L.proj_in_c, ws + w.cin, Cp, T, dt, TDC_ACT_NONE, 1, nullptr, 0, 0, ident, ident, stream));
+        {   // proj_in(cat[q, ctx]) = proj_in_q(q) + (per-frame) proj_in_c(ctx)
+            const tdc_rowmap rmap = {nq, 1, 0, 0};
+            RET_IF(gemm(q16, Cp, L.proj_in_q, ws + w.qin, Cp, qrows, dt, TDC_ACT_NONE, 1, ws + w.cin, Cp, 1, ident, rmap, stream));
+        }
+        for (int tw = 0; tw < 2; ++tw) {
+            tdc_ln_desc d;
+            memset(&d, 0, sizeof(d));
+            d.x = ws + w.aux[tw]; d.ldx = Cp; d.x_f32 = 0; d.y16 = ws + w.xn; d.ldy16 = Cp;
+            d.gamma = m->ones_C; d.beta = m->zeros_C; d.eps = 1e-5f;
+            d.add = L.pos[tw]; d.ldadd = L.ldpos; d.add_period = P; d.add_mode = 1;
+            d.rows = rows; d.cols = C; d.dtype = dt;
+            RET_IF(tdc_layernorm(&d, stream));
+            RET_IF(gemm(ws + w.xn, Cp, L.kv[tw], ws + w.kv[tw], L.kv[tw].n, rows, dt, TDC_ACT_NONE, 0, nullptr, 0, 0, ident, ident, stream));
+        }
+        RET_IF(ln16((const float*)(ws + w.qin), Cp, ws + w.qn, Cp, L.q_ln_g, L.q_ln_b, 1e-5f, qrows, C, dt, stream));
+        RET_IF(gemm(ws + w.qn, Cp, L.q_proj, ws + w.qs, Cp, qrows, dt, TDC_ACT_NONE, 0, nullptr, 0, 0, ident, ident, stream));
+        {
+            tdc_sva_attn_desc a;
+            memset(&a, 0, sizeof(a));
+            a.q = ws + w.qs; a.ldq = Cp; a.kv[0] = ws + w.kv[0]; a.kv[1] = ws + w.kv[1]; a.ldkv = L.kv[0].n;
+            a.mask = mask; a.out = ws + w.att; a.ldo = Cp;
+            a.T = T; a.side = side; a.r = r; a.n_towers = 2; a.dim = C; a.heads = m->heads; a.dtype = dt;
+            if (Cp != C && hipMemsetAsync(ws + w.att, 0, (size_t)qrows * Cp * 2, st) != hipSuccess) return TDC_E_BADARG;
+            RET_IF(tdc_sva_attention(&a, stream));
+        }
+        RET_IF(gemm(ws + w.att, Cp, L.o_proj, ws + w.q2, Cp, qrows, dt, TDC_ACT_NONE, 1, ws + w.qin, Cp, 1, ident, ident, stream));
+        RET_IF(ln16((const float*)(ws + w.q2), Cp, ws + w.qn, Cp, L.norm_g, L.norm_b, 1e-5f, qrows, C, dt, stream));
+        RET_IF(gemm(ws + w.qn, Cp, L.out1, ws + w.mh, Cp, qrows, dt, TDC_ACT_GELU_ERF, 0, nullptr, 0, 0, ident, ident, stream));
+        RET_IF(gemm(ws + w.mh, Cp, L.out2, q16n, Cp, qrows, dt, TDC_ACT_NONE, 0, q16, Cp, 0, ident, ident, stream));
+        cur ^= 1;
+    }
+    // a9: mm_projector
+    RET_IF(gemm(ws + w.q16[cur], Cp, m->mm1, ws + w.mh, m->mm1.n, qrows, dt, TDC_ACT_GELU_ERF, 0, nullptr, 0, 0, ident, ident, stream));
+    return gemm(ws + w.mh, m->mm1.n, m->mm2, out, ldo, qrows, dt, TDC_ACT_NONE, 0, nullptr, 0, 0, ident, ident, stream);
+}

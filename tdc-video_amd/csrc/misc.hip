@@ -324,3 +324,22 @@ extern "C" int tdc_device_info(int* cu_count, size_t* hbm_bytes) {
     if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
     return 0;
 }
+
+// every row of out [rows, ld] (16-bit) := row[0 .. ld): the SVA queries start as `vision_query` on every window of every
+// frame (cambrian_arch.py:1018-1023).  ld % 8 == 0, 16-byte aligned.
+namespace {
+__global__ __launch_bounds__(256) void fill_rows_kernel(const u32x4* __restrict__ row, u32x4* __restrict__ out, int chunks,
+                                                        long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) out[i] = row[i % chunks];
+}
+}  // namespace
+
+extern "C" int tdc_fill_rows(const void* row, void* out, int ld, int rows, void* stream) {
+    if (!row || !out || ld <= 0 || rows <= 0 || (ld & 7) || ((uintptr_t)row & 15) || ((uintptr_t)out & 15)) return TDC_E_BADARG;
+    const int chunks = ld / 8;
+    const long long total = (long long)rows * chunks;
+    hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const u32x4*)row, (u32x4*)out, chunks, total);
+    return (int)hipGetLastError();
+}

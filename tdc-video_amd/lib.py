@@ -80,6 +80,24 @@ class VitModel(C.Structure):
                 ("layers_host", C.POINTER(VitLayer)), ("fused", C.c_int)]
 
 
+class AuxProj(C.Structure):
+    _fields_ = [("fc1", Lin), ("fc2", Lin), ("ln_g", C.c_void_p), ("ln_b", C.c_void_p)]
+
+
+class SvaLayer(C.Structure):
+    _fields_ = [("proj_context", Lin), ("proj_in_c", Lin), ("proj_in_q", Lin),
+                ("pos", C.c_void_p * 2), ("ldpos", C.c_int), ("kv", Lin * 2),
+                ("q_ln_g", C.c_void_p), ("q_ln_b", C.c_void_p), ("q_proj", Lin), ("o_proj", Lin),
+                ("norm_g", C.c_void_p), ("norm_b", C.c_void_p), ("out1", Lin), ("out2", Lin)]
+
+
+class ConnectorModel(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("C", C.c_int), ("side", C.c_int), ("r", C.c_int), ("heads", C.c_int),
+                ("n_layers", C.c_int), ("aux", AuxProj * 2), ("vision_query", C.c_void_p),
+                ("ones_C", C.c_void_p), ("zeros_C", C.c_void_p), ("layers_host", C.POINTER(SvaLayer)),
+                ("mm1", Lin), ("mm2", Lin)]
+
+
 class QformerLayer(C.Structure):
     _fields_ = [("qkv", Lin), ("attn_out", Lin), ("attn_ln_g", C.c_void_p), ("attn_ln_b", C.c_void_p),
                 ("has_cross", C.c_int), ("cross_idx", C.c_int),
@@ -120,6 +138,10 @@ SIGNATURES = {
     "tdc_vit_fwd": (C.c_int, [C.POINTER(VitModel), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
                               C.c_void_p]),
+    "tdc_fill_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "tdc_connector_workspace_bytes": (C.c_size_t, [C.POINTER(ConnectorModel), C.c_int]),
+    "tdc_connector_fwd": (C.c_int, [C.POINTER(ConnectorModel), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "tdc_qformer_workspace_bytes": (C.c_size_t, [C.POINTER(QformerModel), C.c_int, C.c_int, C.c_int, C.c_int]),
     "tdc_qformer_fwd": (C.c_int, [C.POINTER(QformerModel), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                   C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,

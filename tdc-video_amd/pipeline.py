@@ -251,7 +251,74 @@ class VideoEncoder:
         X = ops.gather_rows([feat, self.c.image_newline], idx, len(src), Hp)
         return X, sizes
 
+    # ---- native composite (csrc/api.cpp: tdc_connector_fwd): a6-a9 in one C call ------------------------------------------
+    def _connector_struct(self):
+        """ctypes mirror of tdc_connector_model (cached; keeps the arrays alive)."""
+        if getattr(self, "_conn_struct", None) is not None:
+            return self._conn_struct
+        c = self.c
+
+        def lin(l):
+            return L.Lin(l.w.data_ptr(), l.b.data_ptr() if l.b is not None else None, l.w.shape[0], l.w.shape[1])
+        layers = (L.SvaLayer * len(c.sva))()
+        for i, Lr in enumerate(c.sva):
+            x = L.SvaLayer()
+            x.proj_context, x.proj_in_c, x.proj_in_q = lin(Lr.proj_context), lin(Lr.proj_in_c), lin(Lr.proj_in_q)
+            x.pos[0], x.pos[1], x.ldpos = Lr.pos[0].data_ptr(), Lr.pos[1].data_ptr(), Lr.pos[0].stride(0)
+            x.kv[0], x.kv[1] = lin(Lr.kv[0]), lin(Lr.kv[1])
+            x.q_ln_g, x.q_ln_b = Lr.q_ln[0].data_ptr(), Lr.q_ln[1].data_ptr()
+            x.q_proj, x.o_proj = lin(Lr.q_proj), lin(Lr.o_proj)
+            x.norm_g, x.norm_b = Lr.norm[0].data_ptr(), Lr.norm[1].data_ptr()
+            x.out1, x.out2 = lin(Lr.out1), lin(Lr.out2)
+            layers[i] = x
+        vq = torch.zeros(pad64(c.C), device=self.dev, dtype=self.dtype)
+        vq[: c.C] = c.vision_query.to(self.dtype).to(self.dev)
+        m = L.ConnectorModel()
+        m.dtype, m.C, m.side, m.heads, m.n_layers = ops._dtcode(self.dtype), c.C, self.side, 16, len(c.sva)
+        for i in range(2):
+            a = c.aux[i]
+            m.aux[i] = L.AuxProj(lin(a.fc1), lin(a.fc2), a.ln_g.data_ptr(), a.ln_b.data_ptr())
+        m.vision_query, m.ones_C, m.zeros_C = vq.data_ptr(), c.ones_C.data_ptr(), c.zeros_C.data_ptr()
+        m.layers_host = layers
+        m.mm1, m.mm2 = lin(c.mm1), lin(c.mm2)
+        self._conn_struct = (m, layers, vq)
+        return self._conn_struct
+
+    def _window_mask(self, T, P, image_sizes):
+        side = self.side
+        r = int(round(P ** 0.5)) // side
+        cache, rows = {}, []
+        for t in range(T):
+            key = tuple(image_sizes[t])
+            if key not in cache:
+                m0 = seg.window_mask_bytes(side, r, key)
+                cache[key] = [a + b for a, b in zip(m0, m0)]  # both towers share the geometry (same grid)
+            rows.extend(cache[key])
+        return torch.tensor(rows, dtype=torch.uint8, device=self.dev).contiguous(), r
+
+    def _connector_native(self, sig_feat, dino_feat, T, image_sizes):
+        import ctypes as C
+        m = self._connector_struct()[0]
+        P = sig_feat.shape[0] // T
+        mask, r = self._window_mask(T, P, image_sizes)
+        m.r = r
+        assert dino_feat.shape[0] == T * P and P == (self.side * r) ** 2
+        assert sig_feat.shape[1] >= m.aux[0].fc1.k and dino_feat.shape[1] >= m.aux[1].fc1.k
+        lib = L.load()
+        need = lib.tdc_connector_workspace_bytes(C.byref(m), T)
+        ws = getattr(self, "_conn_ws", None)
+        if ws is None or ws.numel() < need:
+            ws = self._conn_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        out = torch.empty(T * self.side * self.side, pad64(self.c.H), device=self.dev, dtype=self.dtype)
+        L.check(lib.tdc_connector_fwd(C.byref(m), ops._ptr(sig_feat), sig_feat.stride(0), ops._ptr(dino_feat),
+                                      dino_feat.stride(0), T, ops._ptr(mask), ops._ptr(out), out.stride(0), ops._ptr(ws),
+                                      ws.numel(), ops._stream()), "tdc_connector_fwd")
+        return out
+
     def connector(self, sig_feat, dino_feat, T, image_sizes, keep=None):
+        if keep is None and getattr(self, "native_connector", True) and ops.PROFILE is None:
+            feat = self._connector_native(sig_feat, dino_feat, T, image_sizes)
+            return self.unpad_newline(feat, T, image_sizes)
         aux = [self.aux_project(sig_feat, 0), self.aux_project(dino_feat, 1)]
         q = self.sva(aux, T, image_sizes)
         feat = self.mm_project(q)

@@ -483,3 +483,23 @@ def test_native_qformer_composite_equals_kernel_sequence(name, dtype):
         outs.append(enc.encode_video(vid, vid + 0.01, size, len(ids), len(ids) - 1, [int(i) for i in o["prompt_ids"]],
                                      audio=audio))
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_native_connector_composite_equals_kernel_sequence(dtype):
+    """tdc_connector_fwd (C++ composite: aux projectors, global context, SVA layers, mm_projector) launches the same
+    kernels as the per-kernel Python sequence: bit-identical tokens, incl. the landscape fixture (non-trivial window
+    masks)."""
+    for name in ("pipeline_T10_land.npz", "pipeline_T40.npz"):
+        W, o = load_fixture(name)
+        enc = make_encoder(W, pipeline_cfg(o), dtype)
+        vid = torch.from_numpy(synth.video_from_basis(o["video_basis"], o["video_coef"]))[:12]
+        T = vid.shape[0]
+        sig = enc.tower("siglip", vid.cuda())
+        dino = enc.tower("dino", (vid + 0.01).cuda())
+        sizes = [tuple(int(v) for v in o["image_size"])] * T
+        enc.native_connector = True
+        Xa, sa = enc.connector(sig, dino, T, sizes)
+        enc.native_connector = False
+        Xb, sb = enc.connector(sig, dino, T, sizes)
+        assert sa == sb and torch.equal(Xa, Xb), name
