@@ -102,9 +102,12 @@ class VideoEncoder:
         m = self._vit_struct(t, g, g)[0]
         lib = L.load()
         need = lib.tdc_vit_workspace_bytes(C.byref(m), B, H, W)
-        ws = getattr(self, "_vit_ws", None)
+        # one workspace per tower when the towers run concurrently on two streams, otherwise one shared buffer
+        wkey = "_vit_ws_" + t.kind if getattr(self, "two_streams", False) else "_vit_ws"
+        ws = getattr(self, wkey, None)
         if ws is None or ws.numel() < need:
-            ws = self._vit_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+            ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+            setattr(self, wkey, ws)
         D = t.dim
         out = torch.empty(B * out_grid * out_grid, pad64(D), device=self.dev, dtype=self.dtype)
         i0, i1, fr = self._bil(g, out_grid)
