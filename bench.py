@@ -173,7 +173,9 @@ def main():
     ap.add_argument("--frames", type=int, default=512)
     ap.add_argument("--K", type=int, default=144, help="context_token_num (BASELINE configs: 144; reference default 16)")
     ap.add_argument("--hidden", type=int, default=3584, help="LLM embed dim (Qwen2-7B)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp8"],
+                    help="fp8 (BASELINE config 5): e4m3 operands for the towers' LayerNorm-fed GEMMs (qkv, fc1) through "
+                         "v_mfma_f32_16x16x32_fp8_fp8, bf16 everywhere else")
     ap.add_argument("--px", type=int, default=384, help="SigLIP input size (DINO uses px-6: 378); 336 -> 336/336")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tower-batch", type=int, default=512)
@@ -205,7 +207,7 @@ def main():
     from tdc_video_amd.pipeline import VideoEncoder
     from tdc_video_amd import segment as seg
 
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     T, K, H = args.frames, args.K, args.hidden
     px_s = args.px
     px_d = args.px - 6 if args.px == 384 else args.px
@@ -213,7 +215,7 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(0)
     sd = random_state_dict(H, K, dev, gen, siglip_px=px_s)
     enc = VideoEncoder(sd, cfg, dtype=dtype, device=dev, siglip_heads=16, dino_heads=24, qformer_heads=12,
-                       tower_batch=args.tower_batch)
+                       tower_batch=args.tower_batch, fp8_towers=args.dtype == "fp8")
     enc.two_streams = bool(args.two_streams)
     wav = None
     if args.audio:
@@ -296,7 +298,7 @@ def main():
     # process on this image) and committed under profiles/; null when that summary is absent or another workload runs.
     traffic = mfma_busy = kv_busy = None
     pmc = os.path.join(ROOT, "profiles", "r01e_gemm_pmc_summary.json")
-    if os.path.exists(pmc) and (T, K, H, world, args.tower_batch) == (512, 144, 3584, 1, 512):
+    if os.path.exists(pmc) and (T, K, H, world, args.tower_batch, args.dtype) == (512, 144, 3584, 1, 512, "bf16"):
         summ = json.load(open(pmc))
         traffic = round(summ["per_launch_hbm_bytes"])
         # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles) over the same launch list: MFMA pipe occupancy at the
@@ -319,7 +321,7 @@ def main():
         "metric": "frames/sec encoded+compressed (576->K tokens) at T=%d" % T,
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
+        "dtype": "fp8 (e4m3 qkv/fc1 operands) + bf16" if args.dtype == "fp8" else args.dtype, "data": "synthetic",
         "config": {"workload": "one %d-frame video, SigLIP-so400m/14@%d + DINOv2-giant/14@%d towers (729 patches -> 576 "
                                "tokens), SVA 576->144, mm_projector -> H=%d, Q-Former TDC K=%d (N=156, 12 prompt ids), "
                                "random-init weights, frame cap lifted to T, LLM stubbed%s"

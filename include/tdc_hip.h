@@ -59,6 +59,10 @@ typedef struct {
      * with ln_stats [M, 2] = (mean, rstd), ln_c1[n] = sum_k W'[n, k] (of the 16-bit W'), bias = beta W^T + b. */
     void* x16; int ldx16; float* ln_part;
     const float* ln_stats; const float* ln_c1;
+    /* in_fp8 != 0: A and W hold OCP e4m3 bytes (K % 128 == 0, lda / ldw % 16 == 0, both counted in values), accumulated by
+     * v_mfma_f32_16x16x32_fp8_fp8; `dtype` stays the 16-bit type of C / res.  The dequantisation scales ride on the
+     * LayerNorm-fold operands: ln_stats[m] = (0, s_a[m] * s_w) and ln_c1 = 0 give C = act(s_a[m] s_w acc + bias). */
+    int in_fp8;
 } tdc_gemm_desc;
 int tdc_gemm(const tdc_gemm_desc* d, void* stream);
 /* (mean, M2) partials [slots, rows, 2] of `slots` 64-column slots per row -> stats [rows, 2] = (mean, 1 / sqrt(var + eps)), biased
@@ -78,6 +82,10 @@ typedef struct {
     const float* add; int ldadd; int add_period; int add_mode;
     int rows, cols, dtype;
     tdc_rowmap x_map, y_map; /* row r reads x[x_map(r)] and writes y*[y_map(r)] (identity when seg == 0) */
+    /* fp8 output (may be NULL; y16 / y32 may then be NULL too): y8 [rows, ldy8] OCP e4m3 bytes = y / s_a[r] with the
+     * per-row scale s_a[r] = max|y[r]| / 448, pad columns zero; y8_stats[r] = (0, s_a[r] * y8_wscale) is the ln_stats
+     * operand of the fp8-operand tdc_gemm that consumes y8 (y8_wscale = that GEMM's per-tensor weight scale). */
+    void* y8; int ldy8; float* y8_stats; float y8_wscale;
 } tdc_ln_desc;
 int tdc_layernorm(const tdc_ln_desc* d, void* stream);
 
@@ -172,6 +180,9 @@ typedef struct {
      * lin's weight is then W diag(gamma) and its bias beta W^T + b.  qkv_c1 == NULL: this layer's LN1 runs as a kernel
      * (layer 0, whose input comes from the patch embedding). */
     const float *qkv_c1, *fc1_c1;
+    /* fp8 towers (tdc_vit_model.fp8): qkv.w / fc1.w hold e4m3 bytes [n, round_up(k, 128)] with these per-tensor scales;
+     * zeros [>= max n] fp32 zeros (the ln_c1 operand of an fp8-operand tdc_gemm) */
+    float qkv_wscale, fc1_wscale; const float* zeros;
 } tdc_vit_layer;
 typedef struct {
     int dtype, dim, heads, head_dim, n_layers, patch, has_cls;
@@ -183,6 +194,8 @@ typedef struct {
     const float *lnf_g, *lnf_b;      /* final LayerNorm (NULL: take the raw residual stream, SigLIP hidden_states[-1]) */
     const tdc_vit_layer* layers_host;
     int fused;                       /* pre-LayerNorms folded into the qkv / fc1 GEMMs (dim % 64 == 0) */
+    int fp8;                         /* the LayerNorms emit e4m3 rows + per-row scales and the qkv / fc1 GEMMs run on fp8
+                                        operands (dim % 128 == 0; excludes `fused`); everything else stays 16-bit */
 } tdc_vit_model;
 size_t tdc_vit_workspace_bytes(const tdc_vit_model* m, int B, int H, int W);
 /* px [B,3,H,W] (fp32 when px_f32 else 16-bit) -> out [B*out_grid*out_grid, ldo] 16-bit; idx0/idx1/frac: bilinear tables

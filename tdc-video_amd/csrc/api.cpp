@@ -12,7 +12,7 @@ inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline int pad64i(int x) { return (x + 63) / 64 * 64; }
 
 struct VitWs {
-    size_t patches, x32, h16, qkv, attn, mlp, part, stats, total;
+    size_t patches, x32, h16, qkv, attn, mlp, part, stats, total;   // fp8 towers: h16 holds the e4m3 LayerNorm rows
 };
 
 VitWs vit_layout(const tdc_vit_model* m, int B, int H, int W) {
@@ -31,7 +31,7 @@ VitWs vit_layout(const tdc_vit_model* m, int B, int H, int W) {
     w.attn = off;    off += al256(rows * Dp * 2);
     w.mlp = off;     off += al256(rows * mlp_w * 2);
     w.part = off;    off += m->fused ? al256(rows * (size_t)(Dp / 64) * 8) : 0;
-    w.stats = off;   off += m->fused ? al256(rows * 8) : 0;
+    w.stats = off;   off += (m->fused || m->fp8) ? al256(rows * 8) : 0;
     w.total = off;
     return w;
 }
@@ -45,6 +45,26 @@ int gemm(const void* A, int lda, const tdc_lin& L, void* C, int ldc, int M, int 
     d.A = A; d.lda = lda; d.W = L.w; d.ldw = L.k; d.C = C; d.ldc = ldc; d.bias = L.b; d.res = res; d.ldres = ldres;
     d.M = M; d.N = L.n; d.K = L.k; d.dtype = dtype; d.out_f32 = out_f32; d.res_f32 = res_f32; d.act = act;
     d.c_map = cmap; d.r_map = rmap;
+    return tdc_gemm(&d, st);
+}
+
+// LayerNorm -> e4m3 rows + per-row scales (stats) for an fp8-operand GEMM with per-tensor weight scale `wscale`
+int layernorm_fp8(const float* x, int ldx, void* y8, int ldy8, float* stats, float wscale, const float* g, const float* b,
+                  float eps, int rows, int cols, int dtype, void* st) {
+    tdc_ln_desc d;
+    memset(&d, 0, sizeof(d));
+    d.x = x; d.ldx = ldx; d.x_f32 = 1; d.gamma = g; d.beta = b; d.eps = eps;
+    d.rows = rows; d.cols = cols; d.dtype = dtype;
+    d.y8 = y8; d.ldy8 = ldy8; d.y8_stats = stats; d.y8_wscale = wscale;
+    return tdc_layernorm(&d, st);
+}
+
+int gemm_fp8(const void* A8, int lda, const tdc_lin& L, void* C, int ldc, int M, int dtype, int act, const float* stats,
+             const float* zeros, void* st) {
+    tdc_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.A = A8; d.lda = lda; d.W = L.w; d.ldw = L.k; d.C = C; d.ldc = ldc; d.bias = L.b;
+    d.M = M; d.N = L.n; d.K = L.k; d.dtype = dtype; d.act = act; d.in_fp8 = 1; d.ln_stats = stats; d.ln_c1 = zeros;
     return tdc_gemm(&d, st);
 }
 
@@ -246,13 +266,16 @@ extern "C" int tdc_vit_fwd(const tdc_vit_model* m, const void* px, int px_f32, i
     // fused: the block's LayerNorms are folded into the GEMMs around them (tdc_gemm_desc: x16 / ln_part / ln_stats / ln_c1);
     // h16 then holds the 16-bit copy of the residual stream instead of the LayerNorm output
     const bool fused = m->fused != 0;
-    if (fused && (D % 64 != 0)) return TDC_E_BADARG;
+    if ((fused && (D % 64 != 0)) || (m->fp8 && (fused || D % 128 != 0))) return TDC_E_BADARG;
     float* part = (float*)(ws + w.part);
     float* stats = (float*)(ws + w.stats);
     const int slots = D / 64;
     for (int l = 0; l < m->n_layers; ++l) {
         const tdc_vit_layer& L = m->layers_host[l];
-        if (!fused || !L.qkv_c1) {
+        if (m->fp8) {
+            RET_IF(layernorm_fp8(x32, Dp, h16, L.qkv.k, stats, L.qkv_wscale, L.ln1_g, L.ln1_b, m->eps, rows, D, dt, stream));
+            RET_IF(gemm_fp8(h16, L.qkv.k, L.qkv, qkv, L.qkv.n, rows, dt, TDC_ACT_NONE, stats, L.zeros, stream));
+        } else if (!fused || !L.qkv_c1) {
             RET_IF(layernorm(x32, Dp, h16, Dp, L.ln1_g, L.ln1_b, m->eps, rows, D, dt, stream));
             RET_IF(gemm(h16, Dp, L.qkv, qkv, L.qkv.n, rows, dt, TDC_ACT_NONE, 0, nullptr, 0, 0, ident, ident, stream));
         } else {
@@ -280,6 +303,11 @@ extern "C" int tdc_vit_fwd(const tdc_vit_model* m, const void* px, int px_f32, i
             } else {
                 RET_IF(gemm(mlp, L.fc2.k, L.fc2, x32, Dp, rows, dt, TDC_ACT_NONE, 1, x32, Dp, 1, ident, ident, stream));
             }
+        } else if (m->fp8) {
+            RET_IF(gemm(attn, Dp, L.out, x32, Dp, rows, dt, TDC_ACT_NONE, 1, x32, Dp, 1, ident, ident, stream));
+            RET_IF(layernorm_fp8(x32, Dp, h16, L.fc1.k, stats, L.fc1_wscale, L.ln2_g, L.ln2_b, m->eps, rows, D, dt, stream));
+            RET_IF(gemm_fp8(h16, L.fc1.k, L.fc1, mlp, L.fc2.k, rows, dt, m->act, stats, L.zeros, stream));
+            RET_IF(gemm(mlp, L.fc2.k, L.fc2, x32, Dp, rows, dt, TDC_ACT_NONE, 1, x32, Dp, 1, ident, ident, stream));
         } else {
             RET_IF(gemm(attn, Dp, L.out, x32, Dp, rows, dt, TDC_ACT_NONE, 1, x32, Dp, 1, ident, ident, stream));
             RET_IF(layernorm(x32, Dp, h16, Dp, L.ln2_g, L.ln2_b, m->eps, rows, D, dt, stream));

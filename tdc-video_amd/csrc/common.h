@@ -35,6 +35,21 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// fp8 (OCP e4m3) operands: the same 16-byte fragment holds 16 values = two K=32 steps of v_mfma_f32_16x16x32_fp8_fp8
+// (lane l: bytes 8 h .. 8 h + 7 of its fragment are k-slot (l >> 4) of step h).  A and W fragments are cut identically, so
+// the contraction pairs the right bytes whatever the order of K inside the 128-byte row.
+typedef __attribute__((ext_vector_type(2))) long i64x2;
+template <bool FP8, class V8>
+__device__ __forceinline__ f32x4 mma16(V8 a, V8 b, f32x4 c) {
+    if constexpr (FP8) {
+        const i64x2 a2 = __builtin_bit_cast(i64x2, a), b2 = __builtin_bit_cast(i64x2, b);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a2[0], b2[0], c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a2[1], b2[1], c, 0, 0, 0);
+    } else {
+        return mfma16(a, b, c);
+    }
+}
+
 // Activations for GEMM epilogues.  They run once per output element inside an MFMA-bound kernel, so they are written
 // with the two quarter-rate instructions v_exp_f32 / v_rcp_f32 and a handful of FMAs instead of libm calls
 // (erff / tanhf cost 30-40 VALU instructions per element and dominated the fc1 epilogues).

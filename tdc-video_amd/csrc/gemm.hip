@@ -320,7 +320,9 @@ __device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, in
     tm = first + (within - tn * rows);
 }
 
-template <class T>
+// FP8: A and W hold e4m3 bytes; all addressing below stays in 2-byte units (the host passes K / 2, lda / 2, ldw / 2), only
+// the MFMA differs (common.h: mma16).  T remains the 16-bit output / residual type.
+template <class T, bool FP8>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     typedef typename VecOf<T>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(xw[j], xa[i], acc[i][j]);
+                for (int j = 0; j < 4; ++j) acc[i][j] = mma16<FP8>(xw[j], xa[i], acc[i][j]);
         }
         __syncthreads();  // drains the glds of tile kt+1 (vmcnt(0)) and fences the reads of buffer `cur`
     }
@@ -623,7 +625,7 @@ constexpr int T2_BUF = 4 * T2_HALF;           // A0 A1 W0 W1
 constexpr int T2_LDS = 2 * T2_BUF;            // 128 KiB
 
 #define T2_EPI_BARRIER() __builtin_amdgcn_s_barrier()
-template <class T>
+template <class T, bool FP8>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     typedef typename VecOf<T>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -729,7 +731,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                            \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                               \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                               \
-            acc[(MI0) + i][(NJ0) + j] = mfma16(fbx[j][ks], fa[i][ks], acc[(MI0) + i][(NJ0) + j]); \
+            acc[(MI0) + i][(NJ0) + j] = mma16<FP8>(fbx[j][ks], fa[i][ks], acc[(MI0) + i][(NJ0) + j]); \
         __builtin_amdgcn_s_setprio(0);                                              \
     }
 
@@ -825,7 +827,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 // operands already in LDS.  Staging addresses are an SGPR tile base + 32-bit per-lane offsets (a_map must be identity).
 constexpr int T2P_LDS = T2_LDS + 8 * 4096;    // 160 KiB
 
-template <class T, bool LNF>      // LNF: LayerNorm-fold consumer (ln_stats != NULL): 5 more lane-held epilogue operands
+template <class T, bool LNF, bool FP8>  // LNF: LayerNorm-fold consumer (ln_stats != NULL): 5 more lane-held epilogue operands
 __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
     typedef typename VecOf<T>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1105,12 +1107,13 @@ inline bool use_256(int M, int N, int K) {
 unsigned long long* tdc_gemm_diag_stamps = nullptr;   // set by tools/gemm_stamps.cpp
 namespace {
 #endif
-template <class T>
+template <class T, bool FP8>
 int launch(const tdc_gemm_desc* d, hipStream_t st) {
     GemmArgs a;
     a.A = d->A; a.W = d->W; a.C = d->C; a.bias = d->bias; a.res = d->res;
     a.lda = d->lda; a.ldw = d->ldw; a.ldc = d->ldc; a.ldres = d->ldres;
     a.M = d->M; a.N = d->N; a.K = d->K;
+    if (FP8) { a.lda /= 2; a.ldw /= 2; a.K /= 2; }     // kernels address A / W in 2-byte units
     a.out_f32 = d->out_f32; a.res_f32 = d->res_f32; a.act = d->act;
     a.x16 = d->x16; a.ldx16 = d->ldx16; a.ln_part = d->ln_part; a.ln_stats = d->ln_stats; a.ln_c1 = d->ln_c1;
     { const char* e = getenv("TDC_GEMM_DEBUG"); a.debug = e ? atoi(e) : 0; }
@@ -1120,46 +1123,46 @@ int launch(const tdc_gemm_desc* d, hipStream_t st) {
     a.am = {d->a_map.seg, d->a_map.stride, d->a_map.off, d->a_map.inner};
     a.cm = {d->c_map.seg, d->c_map.stride, d->c_map.off, d->c_map.inner};
     a.rm = {d->r_map.seg, d->r_map.stride, d->r_map.off, d->r_map.inner};
-    if (use_256(d->M, d->N, d->K)) {
-        a.tiles_m = (d->M + 255) / 256;
-        a.tiles_n = (d->N + 255) / 256;
+    if (use_256(a.M, a.N, a.K)) {
+        a.tiles_m = (a.M + 255) / 256;
+        a.tiles_n = (a.N + 255) / 256;
         static bool attr256 = false;
         if (!attr256) {
-            HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm256_kernel<T>,
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm256_kernel<T, FP8>,
                                               hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS));
             attr256 = true;
         }
         // persistent form: more tiles than CUs, identity a_map, K >= 128, in-tile byte offsets fit 32 bits
-        const int G = persistent_grid();
         // (the LayerNorm-fold instance only carries the LDS-staged epilogues)
+        const int G = persistent_grid();
         const bool fold_ok = !d->ln_stats || (!(d->ldc & 7) && !((uintptr_t)d->C & 15) &&
                                               d->N % (d->act == TDC_ACT_SWIGLU ? 16 : 8) == 0);
-        if (G > 0 && a.tiles_m * a.tiles_n > G && d->a_map.seg == 0 && d->K >= 128 && fold_ok &&
-            256ll * d->lda * 2 < (1ll << 31) && 256ll * d->ldw * 2 < (1ll << 31)) {
+        if (G > 0 && a.tiles_m * a.tiles_n > G && d->a_map.seg == 0 && a.K >= 128 && fold_ok &&
+            256ll * a.lda * 2 < (1ll << 31) && 256ll * a.ldw * 2 < (1ll << 31)) {
             static bool attr256p = false;
             if (!attr256p) {
-                HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm256p_kernel<T, false>,
+                HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm256p_kernel<T, false, FP8>,
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, T2P_LDS));
-                HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm256p_kernel<T, true>,
+                HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm256p_kernel<T, true, FP8>,
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, T2P_LDS));
                 attr256p = true;
             }
-            if (d->ln_stats) hipLaunchKernelGGL((gemm256p_kernel<T, true>), dim3(G), dim3(512), T2P_LDS, st, a);
-            else hipLaunchKernelGGL((gemm256p_kernel<T, false>), dim3(G), dim3(512), T2P_LDS, st, a);
+            if (d->ln_stats) hipLaunchKernelGGL((gemm256p_kernel<T, true, FP8>), dim3(G), dim3(512), T2P_LDS, st, a);
+            else hipLaunchKernelGGL((gemm256p_kernel<T, false, FP8>), dim3(G), dim3(512), T2P_LDS, st, a);
             return (int)hipGetLastError();
         }
-        hipLaunchKernelGGL(gemm256_kernel<T>, dim3(a.tiles_m * a.tiles_n), dim3(512), T2_LDS, st, a);
+        hipLaunchKernelGGL((gemm256_kernel<T, FP8>), dim3(a.tiles_m * a.tiles_n), dim3(512), T2_LDS, st, a);
         return (int)hipGetLastError();
     }
-    a.tiles_m = (d->M + BM - 1) / BM;
-    a.tiles_n = (d->N + BN - 1) / BN;
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (a.N + BN - 1) / BN;
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_kernel<T, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           4 * TILE_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_kernel<T>, dim3(a.tiles_m * a.tiles_n), dim3(256), 4 * TILE_BYTES, st, a);
+    hipLaunchKernelGGL((gemm_kernel<T, FP8>), dim3(a.tiles_m * a.tiles_n), dim3(256), 4 * TILE_BYTES, st, a);
     return (int)hipGetLastError();
 }
 
@@ -1167,11 +1170,13 @@ int launch(const tdc_gemm_desc* d, hipStream_t st) {
 
 extern "C" int tdc_gemm(const tdc_gemm_desc* d, void* stream) {
     if (!d || !d->A || !d->W || !d->C || d->M <= 0 || d->N <= 0 || d->K <= 0) return TDC_E_BADARG;
-    if (d->K % BK != 0 || d->N % 4 != 0 || (d->act == TDC_ACT_SWIGLU && d->N % 8 != 0)) {
-        fprintf(stderr, "[tdc_hip] tdc_gemm: K %% 64 / N %% 4 violated (M=%d N=%d K=%d)\n", d->M, d->N, d->K);
+    const int kmul = d->in_fp8 ? 2 * BK : BK;                  /* one 128-byte K tile: 64 16-bit or 128 fp8 values */
+    if (d->K % kmul != 0 || d->N % 4 != 0 || (d->act == TDC_ACT_SWIGLU && d->N % 8 != 0)) {
+        fprintf(stderr, "[tdc_hip] tdc_gemm: K %% %d / N %% 4 violated (M=%d N=%d K=%d)\n", kmul, d->M, d->N, d->K);
         return TDC_E_BADARG;
     }
-    if ((d->lda % 8) || (d->ldw % 8) || (d->ldc % 4) || (d->res && (d->ldres % 4)) || d->ldw < d->K) return TDC_E_BADARG;
+    const int amul = d->in_fp8 ? 16 : 8;                       /* rows start on 16-byte boundaries */
+    if ((d->lda % amul) || (d->ldw % amul) || (d->ldc % 4) || (d->res && (d->ldres % 4)) || d->ldw < d->K) return TDC_E_BADARG;
     /* lda < K is legal: rows of A may overlap (sliding-window views, e.g. the BEATs conv positional embedding) */
     if (d->act != TDC_ACT_NONE && d->res) return TDC_E_BADARG;  /* activation epilogues take no residual */
     if (d->x16) {   /* LayerNorm fusion, producer: fp32 residual-stream update with identity row maps, whole 64-column slots */
@@ -1186,7 +1191,12 @@ extern "C" int tdc_gemm(const tdc_gemm_desc* d, void* stream) {
             return TDC_E_BADARG;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (d->dtype == TDC_F16) return launch<f16>(d, st);
-    if (d->dtype == TDC_BF16) return launch<bf16>(d, st);
+    if (d->in_fp8) {
+        if (d->dtype == TDC_F16) return launch<f16, true>(d, st);
+        if (d->dtype == TDC_BF16) return launch<bf16, true>(d, st);
+        return TDC_E_BADARG;
+    }
+    if (d->dtype == TDC_F16) return launch<f16, false>(d, st);
+    if (d->dtype == TDC_BF16) return launch<bf16, false>(d, st);
     return TDC_E_BADARG;
 }

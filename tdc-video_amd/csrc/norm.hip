@@ -16,6 +16,9 @@ struct LnArgs {
     const float* add; int ldadd; int add_period; int add_mode; int add_side;
     int rows, cols, pad_cols;
     RowMap xm, ym;
+    // fp8 (OCP e4m3) output for an fp8-operand GEMM: y8[row] = LN(x) / s_a with s_a = max|LN(x)| / 448 per row, and
+    // st8[row] = (0, s_a * wscale): the (mean, rstd) pair the consuming tdc_gemm folds into its epilogue
+    unsigned char* y8; int ldy8; float* st8; float wscale;
 };
 
 // NV4 = number of 4-column groups per lane: lane l owns columns 4*(l + 64*i) .. +3 (16-byte fp32 / 8-byte 16-bit
@@ -85,7 +88,34 @@ __global__ __launch_bounds__(256) void ln_kernel(LnArgs p) {
                 *(v4*)((T*)p.y16 + yrow * p.ldy16 + c) = h;
             }
             if (p.y32) *(f32x4*)(p.y32 + yrow * p.ldy32 + c) = o;
+            if (p.y8) v[i] = o;                 // keep the normalised row for the quantisation pass
         }
+    }
+    if (p.y8) {
+        float amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) {
+            const int c = (lane + i * 64) * 4;
+            if (c < p.cols)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(v[i][e]));
+        }
+        amax = wave_max(amax);
+        const float sa = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+        const float inv = 1.0f / sa;
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) {
+            const int c = (lane + i * 64) * 4;
+            if (c < p.pad_cols) {
+                int w = 0;
+                if (c < p.cols) {
+                    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][0] * inv, v[i][1] * inv, w, false);
+                    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][2] * inv, v[i][3] * inv, w, true);
+                }
+                *(int*)(p.y8 + yrow * p.ldy8 + c) = w;
+            }
+        }
+        if (lane == 0) *(float2*)(p.st8 + 2 * yrow) = make_float2(0.f, sa * p.wscale);
     }
 }
 
@@ -175,8 +205,10 @@ __global__ __launch_bounds__(256) void qembed_kernel(QeArgs p) {
 }  // namespace
 
 extern "C" int tdc_layernorm(const tdc_ln_desc* d, void* stream) {
-    if (!d || !d->x || d->rows <= 0 || d->cols <= 0 || (!d->y16 && !d->y32)) return TDC_E_BADARG;
+    if (!d || !d->x || d->rows <= 0 || d->cols <= 0 || (!d->y16 && !d->y32 && !d->y8)) return TDC_E_BADARG;
+    if (d->y8 && (!d->y8_stats || (d->ldy8 & 3) || ((uintptr_t)d->y8 & 3) || ((uintptr_t)d->y8_stats & 7))) return TDC_E_BADARG;
     LnArgs a;
+    a.y8 = (unsigned char*)d->y8; a.ldy8 = d->ldy8; a.st8 = d->y8_stats; a.wscale = d->y8_wscale;
     a.x = d->x; a.ldx = d->ldx; a.x_f32 = d->x_f32;
     a.y16 = d->y16; a.ldy16 = d->ldy16; a.y32 = d->y32; a.ldy32 = d->ldy32;
     a.gamma = d->gamma; a.beta = d->beta; a.eps = d->eps;
@@ -193,7 +225,7 @@ extern "C" int tdc_layernorm(const tdc_ln_desc* d, void* stream) {
     a.ym = {d->y_map.seg, d->y_map.stride, d->y_map.off, d->y_map.inner};
     a.pad_cols = (d->cols + 63) / 64 * 64;
     int ldmin = a.pad_cols;
-    if ((d->y16 && d->ldy16 < ldmin) || (d->y32 && d->ldy32 < ldmin)) {
+    if ((d->y16 && d->ldy16 < ldmin) || (d->y32 && d->ldy32 < ldmin) || (d->y8 && d->ldy8 < ldmin)) {
         // outputs narrower than the padded width: only write the real columns
         a.pad_cols = d->cols;
     }

@@ -21,7 +21,7 @@ class GemmDesc(C.Structure):
                 ("dtype", C.c_int), ("out_f32", C.c_int), ("res_f32", C.c_int), ("act", C.c_int),
                 ("a_map", RowMap), ("c_map", RowMap), ("r_map", RowMap),
                 ("x16", C.c_void_p), ("ldx16", C.c_int), ("ln_part", C.c_void_p),
-                ("ln_stats", C.c_void_p), ("ln_c1", C.c_void_p)]
+                ("ln_stats", C.c_void_p), ("ln_c1", C.c_void_p), ("in_fp8", C.c_int)]
 
 
 class LnDesc(C.Structure):
@@ -30,7 +30,8 @@ class LnDesc(C.Structure):
                 ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float),
                 ("add", C.c_void_p), ("ldadd", C.c_int), ("add_period", C.c_int), ("add_mode", C.c_int),
                 ("rows", C.c_int), ("cols", C.c_int), ("dtype", C.c_int),
-                ("x_map", RowMap), ("y_map", RowMap)]
+                ("x_map", RowMap), ("y_map", RowMap),
+                ("y8", C.c_void_p), ("ldy8", C.c_int), ("y8_stats", C.c_void_p), ("y8_wscale", C.c_float)]
 
 
 class AttnDesc(C.Structure):
@@ -69,7 +70,8 @@ class Lin(C.Structure):
 class VitLayer(C.Structure):
     _fields_ = [("ln1_g", C.c_void_p), ("ln1_b", C.c_void_p), ("ln2_g", C.c_void_p), ("ln2_b", C.c_void_p),
                 ("qkv", Lin), ("out", Lin), ("fc1", Lin), ("fc2", Lin),
-                ("qkv_c1", C.c_void_p), ("fc1_c1", C.c_void_p)]
+                ("qkv_c1", C.c_void_p), ("fc1_c1", C.c_void_p),
+                ("qkv_wscale", C.c_float), ("fc1_wscale", C.c_float), ("zeros", C.c_void_p)]
 
 
 class VitModel(C.Structure):
@@ -77,7 +79,7 @@ class VitModel(C.Structure):
                 ("n_layers", C.c_int), ("patch", C.c_int), ("has_cls", C.c_int), ("act", C.c_int),
                 ("eps", C.c_float), ("patch_lin", Lin), ("pos", C.c_void_p), ("ldpos", C.c_int),
                 ("cls_row", C.c_void_p), ("lnf_g", C.c_void_p), ("lnf_b", C.c_void_p),
-                ("layers_host", C.POINTER(VitLayer)), ("fused", C.c_int)]
+                ("layers_host", C.POINTER(VitLayer)), ("fused", C.c_int), ("fp8", C.c_int)]
 
 
 class AuxProj(C.Structure):

@@ -77,21 +77,32 @@ def _map_max(m, M):
     return max(f(i) for i in cand)
 
 
+FP8_DTYPES = (torch.uint8, torch.float8_e4m3fn)
+
+
 def gemm(a, w, bias=None, act=L.ACT_NONE, res=None, out=None, out_f32=False, M=None, a_map=None, c_map=None,
-         r_map=None, out_rows=None, x16=None, ln_part=None, ln_stats=None, ln_c1=None):
+         r_map=None, out_rows=None, x16=None, ln_part=None, ln_stats=None, ln_c1=None, out_dtype=None):
     """out[c_map(m)] = act(a[a_map(m)] @ w.T + bias) + res[r_map(m)].  a [Ra, lda], w [N, K] (both 16-bit).
     LayerNorm fusion (include/tdc_hip.h): x16 / ln_part = producer outputs (16-bit copy of the fp32 result, per-slot
-    (mean, M2) partials [N/64, M, 2]); ln_stats [M, 2] / ln_c1 [N] = consumer inputs (a = raw rows, w = folded weight)."""
+    (mean, M2) partials [N/64, M, 2]); ln_stats [M, 2] / ln_c1 [N] = consumer inputs (a = raw rows, w = folded weight).
+    fp8: a and w hold OCP e4m3 bytes (uint8 / float8_e4m3fn tensors); `out_dtype` names the 16-bit output type and the
+    dequantisation scales come in through ln_stats[m] = (0, s_a[m] * s_w), ln_c1 = 0."""
     _chk2d(a, "a"); _chk2d(w, "w")
     N, K = w.shape
-    assert a.dtype == w.dtype and K % 64 == 0 and a.shape[1] >= K, (a.shape, w.shape)
+    fp8 = a.dtype in FP8_DTYPES
+    if fp8:
+        assert w.dtype in FP8_DTYPES and K % 128 == 0 and out_dtype in (torch.float16, torch.bfloat16)
+        assert ln_stats is not None and res is None and not out_f32, "fp8 operands carry their scales in ln_stats"
+    else:
+        out_dtype = a.dtype
+    assert (fp8 or a.dtype == w.dtype) and K % 64 == 0 and a.shape[1] >= K, (a.shape, w.shape)
     if M is None:
         M = a.shape[0]
     assert _map_max(a_map, M) < a.shape[0], "a_map out of range"
     n_out = N // 2 if act == L.ACT_SWIGLU else N
     if out is None:
         rows = out_rows if out_rows is not None else M
-        out = torch.empty(rows, n_out, device=a.device, dtype=torch.float32 if out_f32 else a.dtype)
+        out = torch.empty(rows, n_out, device=a.device, dtype=torch.float32 if out_f32 else out_dtype)
     _chk2d(out, "out")
     assert out.shape[1] >= n_out and _map_max(c_map, M) < out.shape[0], "out too small"
     assert (out.dtype == torch.float32) == bool(out_f32)
@@ -110,7 +121,8 @@ def gemm(a, w, bias=None, act=L.ACT_NONE, res=None, out=None, out_f32=False, M=N
         if not d.res_f32:
             assert res.dtype == a.dtype
     d.M, d.N, d.K = M, N, K
-    d.dtype, d.out_f32, d.act = _dt(a), int(out_f32), act
+    d.dtype, d.out_f32, d.act = _dtcode(out_dtype), int(out_f32), act
+    d.in_fp8 = int(fp8)
     d.a_map, d.c_map, d.r_map = _map(a_map), _map(c_map), _map(r_map)
     if x16 is not None:
         _chk2d(x16, "x16")
@@ -144,8 +156,11 @@ def ln_finalize(ln_part, slots, rows, eps, stats=None):
 
 
 def layernorm(x, gamma, beta, eps, cols, dtype, y16=None, y32=None, add=None, add_period=0, add_mode=0,
-              want16=True, want32=False, rows=None, x_map=None, y_map=None):
-    """LayerNorm over the first `cols` columns of x [rows, ld] (fp32 or 16-bit) -> (y16, y32)."""
+              want16=True, want32=False, rows=None, x_map=None, y_map=None, y8=None, y8_stats=None, y8_wscale=1.0):
+    """LayerNorm over the first `cols` columns of x [rows, ld] (fp32 or 16-bit) -> (y16, y32).  y8 [rows, ld] uint8 +
+    y8_stats [rows, 2]: e4m3 output with per-row scales for an fp8-operand GEMM (include/tdc_hip.h)."""
+    if y8 is not None:
+        want16 = want16 and y16 is not None
     _chk2d(x, "x")
     rows = x.shape[0] if rows is None else rows
     ld = pad64(cols)
@@ -171,6 +186,12 @@ def layernorm(x, gamma, beta, eps, cols, dtype, y16=None, y32=None, add=None, ad
         d.add, d.ldadd, d.add_period, d.add_mode = add.data_ptr(), add.stride(0), add_period, add_mode
         assert add.shape[0] >= (4 if add_mode == 1 else add_period)
     d.rows, d.cols, d.dtype = rows, cols, _dtcode(dtype)
+    if y8 is not None:
+        _chk2d(y8, "y8")
+        assert y8.dtype in FP8_DTYPES and y8.shape[0] > ymax and y8.shape[1] >= cols
+        assert y8_stats is not None and y8_stats.dtype == torch.float32 and y8_stats.is_contiguous()
+        assert y8_stats.numel() >= 2 * (ymax + 1)
+        d.y8, d.ldy8, d.y8_stats, d.y8_wscale = y8.data_ptr(), y8.stride(0), y8_stats.data_ptr(), float(y8_wscale)
     L.check(L.load().tdc_layernorm(C.byref(d), _stream()), "tdc_layernorm")
     return y16, y32
 

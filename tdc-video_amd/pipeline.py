@@ -20,8 +20,10 @@ from .weights import pad64
 
 class VideoEncoder:
     def __init__(self, sd, cfg, dtype=torch.float16, device="cuda", siglip_heads=16, dino_heads=24,
-                 qformer_heads=12, tower_batch=64):
-        """sd: reference-named state dict without the leading 'model.'; cfg: dict of reference config keys."""
+                 qformer_heads=12, tower_batch=64, fp8_towers=False):
+        """sd: reference-named state dict without the leading 'model.'; cfg: dict of reference config keys.
+        fp8_towers (BASELINE config 5): the towers' LayerNorms emit e4m3 rows with per-row scales and the qkv / fc1 GEMMs
+        run on fp8 operands (v_mfma_f32_16x16x32_fp8_fp8); everything else stays in `dtype`."""
         self.cfg = dict(cfg)
         self.dtype, self.dev = dtype, torch.device(device)
         self.tower_batch = tower_batch
@@ -30,9 +32,9 @@ class VideoEncoder:
         d_sd = Wt._strip(sd, "vision_tower_aux_list.1.vision_tower.")
         self.towers = {}
         if s_sd:
-            self.towers["siglip"] = Wt.prep_siglip(s_sd, siglip_heads, dtype, self.dev)
+            self.towers["siglip"] = Wt.prep_siglip(s_sd, siglip_heads, dtype, self.dev, fp8=fp8_towers)
         if d_sd:
-            self.towers["dino"] = Wt.prep_dino(d_sd, dino_heads, dtype, self.dev)
+            self.towers["dino"] = Wt.prep_dino(d_sd, dino_heads, dtype, self.dev, fp8=fp8_towers)
         self.c = Wt.prep_connector(sd, cfg, dtype, self.dev)
         tok = cfg.get("mm_vision_tower_aux_token_len_list", [576, 576])
         self.out_grid = [int(round(t ** 0.5)) for t in tok]
@@ -77,7 +79,9 @@ class VideoEncoder:
             layers[i] = L.VitLayer(Lr.ln1_g.data_ptr(), Lr.ln1_b.data_ptr(), Lr.ln2_g.data_ptr(), Lr.ln2_b.data_ptr(),
                                    lin(Lr.qkv), lin(Lr.out), lin(Lr.fc1), lin(Lr.fc2),
                                    Lr.qkv_c1.data_ptr() if Lr.qkv_c1 is not None else None,
-                                   Lr.fc1_c1.data_ptr() if Lr.fc1_c1 is not None else None)
+                                   Lr.fc1_c1.data_ptr() if Lr.fc1_c1 is not None else None,
+                                   Lr.qkv.wscale or 0.0, Lr.fc1.wscale or 0.0,
+                                   Lr.fc1.zeros.data_ptr() if Lr.fc1.zeros is not None else None)
         m = L.VitModel()
         m.dtype = ops._dtcode(self.dtype)
         m.dim, m.heads, m.head_dim, m.n_layers, m.patch, m.has_cls = t.dim, t.heads, t.head_dim, len(t.layers), t.patch, \
@@ -91,6 +95,7 @@ class VideoEncoder:
         m.lnf_g, m.lnf_b = (fl[0].data_ptr(), fl[1].data_ptr()) if fl else (None, None)
         m.layers_host = layers
         m.fused = int(bool(t.fused))
+        m.fp8 = int(bool(t.get("fp8")))
         cache[(gh, gw)] = (m, layers, pos, cls_row)
         return cache[(gh, gw)]
 
@@ -148,8 +153,15 @@ class VideoEncoder:
         part = torch.empty(slots, B * S, 2, device=dev, dtype=torch.float32) if fused else None
         stats = torch.empty(B * S, 2, device=dev, dtype=torch.float32) if fused else None
         emit = dict(x16=h16, ln_part=part) if fused else {}
+        fp8 = bool(t.get("fp8"))
+        if fp8:     # e4m3 LayerNorm rows (per-row scales in `stats`) for the fp8-operand qkv / fc1 GEMMs
+            h8 = torch.empty(B * S, t.layers[0].qkv.w.shape[1], device=dev, dtype=torch.uint8)
+            stats = torch.empty(B * S, 2, device=dev, dtype=torch.float32)
         for li, Lr in enumerate(t.layers):
-            if Lr.qkv_c1 is None:
+            if fp8:
+                ops.layernorm(x32, Lr.ln1_g, Lr.ln1_b, t.eps, D, dt, y8=h8, y8_stats=stats, y8_wscale=Lr.qkv.wscale)
+                ops.gemm(h8, Lr.qkv.w, Lr.qkv.b, out=qkv, ln_stats=stats, ln_c1=Lr.qkv.zeros, out_dtype=dt)
+            elif Lr.qkv_c1 is None:
                 ops.layernorm(x32, Lr.ln1_g, Lr.ln1_b, t.eps, D, dt, y16=h16)
                 ops.gemm(h16, Lr.qkv.w, Lr.qkv.b, out=qkv)
             else:
@@ -161,6 +173,9 @@ class VideoEncoder:
             if fused:
                 ops.ln_finalize(part, slots, B * S, t.eps, stats)
                 ops.gemm(h16, Lr.fc1.w, Lr.fc1.b, act=act, out=mlp, ln_stats=stats, ln_c1=Lr.fc1_c1)
+            elif fp8:
+                ops.layernorm(x32, Lr.ln2_g, Lr.ln2_b, t.eps, D, dt, y8=h8, y8_stats=stats, y8_wscale=Lr.fc1.wscale)
+                ops.gemm(h8, Lr.fc1.w, Lr.fc1.b, act=act, out=mlp, ln_stats=stats, ln_c1=Lr.fc1.zeros, out_dtype=dt)
             else:
                 ops.layernorm(x32, Lr.ln2_g, Lr.ln2_b, t.eps, D, dt, y16=h16)
                 ops.gemm(h16, Lr.fc1.w, Lr.fc1.b, act=act, out=mlp)

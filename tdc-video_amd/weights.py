@@ -21,10 +21,11 @@ def pad64(n):
 
 class Lin:
     """Prepared nn.Linear: w [n_pad, k_pad] 16-bit, b fp32 [n_pad] or None."""
-    __slots__ = ("w", "b", "n", "k")
+    __slots__ = ("w", "b", "n", "k", "wscale", "zeros")
 
-    def __init__(self, w, b, n, k):
+    def __init__(self, w, b, n, k, wscale=None, zeros=None):
         self.w, self.b, self.n, self.k = w, b, n, k
+        self.wscale, self.zeros = wscale, zeros     # fp8 weights (to_fp8): per-tensor scale, zero ln_c1 vector
 
 
 def make_lin(W, b, dtype, dev, row_scale=None, col_scale=None, col_shift=None, n_pad=None, k_pad=None):
@@ -71,6 +72,26 @@ def stack_lins(parts, dtype, dev, k_pad=None, n_pad=None):
     Wc = torch.cat(Ws, 0)
     bc = torch.cat(bs, 0) if any_b else None
     return make_lin(Wc, bc, dtype, dev, k_pad=k_pad, n_pad=n_pad)
+
+
+def to_fp8(lin, dev):
+    """16-bit prepared Lin -> fp8-operand Lin: w = e4m3(W / s_w) bytes [n_pad, round_up(k, 128)] with the per-tensor scale
+    s_w = max|W| / 448 (tdc_gemm_desc.in_fp8).  The activation side is quantised per row by the LayerNorm kernel
+    (tdc_ln_desc.y8), whose y8_stats carry s_a * s_w into the GEMM epilogue."""
+    W = lin.w.float()
+    amax = float(W.abs().max())
+    sw = amax / 448.0 if amax > 0 else 1.0
+    n_pad, k_pad = W.shape[0], (W.shape[1] + 127) // 128 * 128
+    W8 = torch.zeros(n_pad, k_pad, dtype=torch.uint8, device=W.device)
+    W8[:, : W.shape[1]] = (W / sw).to(torch.float8_e4m3fn).view(torch.uint8)
+    W8 = W8.to(dev).contiguous()
+    W8._real_nk = getattr(lin.w, "_real_nk", (lin.n, lin.k))
+    return Lin(W8, lin.b, lin.n, lin.k, wscale=sw, zeros=torch.zeros(n_pad, dtype=torch.float32, device=dev))
+
+
+def fp8_enabled(dim, requested):
+    """fp8 (e4m3) operands for the GEMMs fed by a LayerNorm (qkv, fc1): widths that are whole 128-byte K tiles."""
+    return bool(requested) and dim % 128 == 0
 
 
 def fold_c1(lin):
@@ -137,13 +158,14 @@ def _strip(sd, prefix):
 
 
 # ---------------------------------------------------------------------------------------------------- towers
-def prep_siglip(sd, heads, dtype, dev, patch=14, eps=1e-6):
+def prep_siglip(sd, heads, dtype, dev, patch=14, eps=1e-6, fp8=False):
     """sd: HF SiglipVisionModel state dict (4.46 'vision_model.' prefix accepted).  siglip_encoder.py:71-78."""
     sd = {k.replace("vision_model.", ""): v for k, v in sd.items()}
     Wp = sd["embeddings.patch_embedding.weight"]
     D = Wp.shape[0]
     t = Namespace(kind="siglip", dim=D, heads=heads, head_dim=D // heads, patch=patch, eps=eps, has_cls=0,
-                  act="gelu_tanh", final_ln=None, fused=ln_fusion_enabled(D))
+                  act="gelu_tanh", final_ln=None, fp8=fp8_enabled(D, fp8))
+    t.fused = ln_fusion_enabled(D) and not t.fp8
     t.patch_lin = make_lin(Wp.reshape(D, -1), sd["embeddings.patch_embedding.bias"], dtype, dev)
     t.pos_table = sd["embeddings.position_embedding.weight"].detach().float().cpu()  # [P, D]
     t.layers = []
@@ -164,18 +186,21 @@ def prep_siglip(sd, heads, dtype, dev, patch=14, eps=1e-6):
         Lr.fc1 = make_lin(sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"], dtype, dev, **f2)
         Lr.fc1_c1 = fold_c1(Lr.fc1) if f2 else None
         Lr.fc2 = make_lin(sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"], dtype, dev)
+        if t.fp8:
+            Lr.qkv, Lr.fc1 = to_fp8(Lr.qkv, dev), to_fp8(Lr.fc1, dev)
         t.layers.append(Lr)
         i += 1
     t.mlp = t.layers[0].fc1.n if t.layers else 0
     return t
 
 
-def prep_dino(sd, heads, dtype, dev, patch=14, eps=1e-6):
+def prep_dino(sd, heads, dtype, dev, patch=14, eps=1e-6, fp8=False):
     """sd: HF Dinov2Model state dict.  dino_encoder.py:109-120."""
     Wp = sd["embeddings.patch_embeddings.projection.weight"]
     D = Wp.shape[0]
     t = Namespace(kind="dino", dim=D, heads=heads, head_dim=D // heads, patch=patch, eps=eps, has_cls=1,
-                  act="swiglu", fused=ln_fusion_enabled(D))
+                  act="swiglu", fp8=fp8_enabled(D, fp8))
+    t.fused = ln_fusion_enabled(D) and not t.fp8
     t.patch_lin = make_lin(Wp.reshape(D, -1), sd["embeddings.patch_embeddings.projection.bias"], dtype, dev)
     t.pos_table = sd["embeddings.position_embeddings"].detach().float().cpu()[0]  # [1+n*n, D]
     t.cls = sd["embeddings.cls_token"].detach().float().cpu().flatten()
@@ -212,6 +237,8 @@ def prep_dino(sd, heads, dtype, dev, patch=14, eps=1e-6):
                               row_scale=sd[p + "layer_scale2.lambda1"])
             t.act = "gelu_erf"
         Lr.fc1_c1 = fold_c1(Lr.fc1) if f2 else None
+        if t.fp8:
+            Lr.qkv, Lr.fc1 = to_fp8(Lr.qkv, dev), to_fp8(Lr.fc1, dev)
         t.layers.append(Lr)
         i += 1
     t.final_ln = (vec32(sd["layernorm.weight"], dev), vec32(sd["layernorm.bias"], dev))

@@ -167,6 +167,56 @@ def test_gemm_layernorm_fusion(ops, dtype, M):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M", [300, 8192, 80 * 256 - 19])
+def test_gemm_fp8_operands(ops, dtype, M):
+    """A and W as OCP e4m3 bytes through v_mfma_f32_16x16x32_fp8_fp8 (all three GEMM kernels), per-row activation scale x
+    per-tensor weight scale applied through the LayerNorm-fold operands.  The reference is the SAME quantised operands
+    multiplied in fp32, so the tolerance is the 16-bit output rounding, not the fp8 quantisation."""
+    from tdc_video_amd import lib as L
+    g = torch.Generator(device="cuda").manual_seed(21)
+    K, N = 1152, 1216
+    x = torch.randn(M, K, device="cuda", generator=g) * (0.5 + torch.rand(M, 1, device="cuda", generator=g))
+    w = torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)
+    b = torch.randn(N, device="cuda", generator=g)
+    sa = x.abs().amax(1) / 448.0
+    sw = (w.abs().max() / 448.0).item()
+    x8 = (x / sa[:, None]).to(torch.float8_e4m3fn)
+    w8 = (w / sw).to(torch.float8_e4m3fn)
+    stats = torch.stack([torch.zeros_like(sa), sa * sw], 1).contiguous()
+    c1 = torch.zeros(N, device="cuda")
+    lin = (x8.float() * sa[:, None]) @ (w8.float() * sw).t() + b
+    for act, want in ((L.ACT_NONE, lin), (L.ACT_GELU_TANH, F.gelu(lin, approximate="tanh")),
+                      (L.ACT_SWIGLU, F.silu(lin[:, 0::2]) * lin[:, 1::2])):
+        out = ops.gemm(x8, w8, b, act=act, ln_stats=stats, ln_c1=c1, out_dtype=dtype)
+        assert out.dtype == dtype and relerr(out, want) < tol(dtype), act
+    # and the quantisation itself is at the e4m3 level (3 mantissa bits) on the linear output
+    assert relerr(lin, x @ w.t() + b) < 5e-2
+
+
+@pytest.mark.parametrize("cols", [1152, 1536])
+def test_layernorm_fp8_output(ops, cols):
+    """tdc_layernorm's e4m3 output: y8 = LN(x) / s_a with the per-row scale s_a = max|LN(x)| / 448 (so the row maximum lands
+    on the largest e4m3 value), y8_stats = (0, s_a * wscale); dequantised it matches the fp32 LayerNorm to e4m3 precision
+    and equals torch's own e4m3 rounding of the scaled row."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    rows, eps, ws = 777, 1e-6, 0.0123
+    x = torch.randn(rows, cols, device="cuda", generator=g) * 3 + 0.5
+    gm = 1.0 + 0.1 * torch.randn(cols, device="cuda", generator=g)
+    bt = 0.1 * torch.randn(cols, device="cuda", generator=g)
+    y8 = torch.empty(rows, cols, device="cuda", dtype=torch.uint8)
+    st = torch.empty(rows, 2, device="cuda")
+    ops.layernorm(x, gm, bt, eps, cols, torch.bfloat16, y8=y8, y8_stats=st, y8_wscale=ws)
+    ref = F.layer_norm(x, (cols,), gm, bt, eps)
+    sa = ref.abs().amax(1) / 448.0
+    assert torch.count_nonzero(st[:, 0]) == 0
+    assert ((st[:, 1] / ws - sa).abs() / sa).max().item() < 1e-5
+    deq = y8.view(torch.float8_e4m3fn).float() * (st[:, 1] / ws)[:, None]
+    assert relerr(deq, ref) < 2 ** -4                    # half an e4m3 ulp at the top of the range
+    want = (ref / (st[:, 1] / ws)[:, None]).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert (want != y8).float().mean().item() < 1e-3      # same rounding as torch's conversion (ties / 1-ulp LN noise aside)
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_gemm_row_maps(ops, dtype):
     g = torch.Generator(device="cuda").manual_seed(2)
     F_, S, Kq, D, N = 5, 11, 4, 128, 64

@@ -136,6 +136,44 @@ def test_towers_natural_scale(kind, D, heads, mlp, px, fuse, dtype, monkeypatch)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("kind,D,heads,mlp,px", [("siglip", 128, 2, 272, 126), ("dino", 256, 4, 344, 126)])
+def test_towers_fp8_operands(kind, D, heads, mlp, px, dtype):
+    """BASELINE config 5's fp8 MFMA path: the towers' LayerNorms emit e4m3 rows with per-row scales and the qkv / fc1
+    GEMMs run on fp8 operands (per-tensor weight scales); HIP vs the fp32 oracle (tolerance: e4m3's 3 mantissa bits on
+    two of the four GEMM inputs of every block), and the C++ composite equals the per-kernel sequence bit for bit."""
+    import tdc_video_amd  # noqa: F401
+    from tdc_video_amd import weights as Wt
+    from tdc_video_amd.pipeline import VideoEncoder
+    g = torch.Generator().manual_seed(12)
+    grid = px // 14
+    sd = _rand_tower_sd(kind, D, heads, mlp, 3, grid if kind == "siglip" else 5, g)
+    pixels = torch.rand(5, 3, px, px, generator=g) * 2 - 1
+    out_grid = 8 if grid > 8 else grid
+    fn = oracle.siglip_tower if kind == "siglip" else oracle.dino_tower
+    ref, _ = fn(pixels, sd, heads, interp_tokens=out_grid * out_grid)
+    enc = VideoEncoder.__new__(VideoEncoder)
+    enc.dtype, enc.dev, enc.tower_batch = dtype, torch.device("cuda"), 3
+    enc._tables = {}
+    enc.out_grid = [out_grid, out_grid]
+    t = (Wt.prep_siglip if kind == "siglip" else Wt.prep_dino)(sd, heads, dtype, enc.dev, fp8=True)
+    assert t.fp8 and t.layers[0].qkv.w.dtype == torch.uint8
+    enc.towers = {kind: t}
+    enc.native_towers = True
+    a = enc.tower(kind, pixels.cuda())
+    enc.native_towers = False
+    b = enc.tower(kind, pixels.cuda())
+    assert torch.equal(a, b)
+    got = a[:, :D].reshape(5, out_grid * out_grid, D).float().cpu()
+    # e4m3 products carry ~2^-4 relative noise each and a random-init tower has no correlated signal to average it
+    # against, so the yardstick is the RMS error relative to the RMS of the output (max error: a few sigma of it)
+    rms = ((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    print("fp8 tower %s D=%d %s: rel RMS err %.3e, max err / max|ref| %.3e" % (kind, D, dtype, rms, rel(got, ref)))
+    # measured: SigLIP-like (GELU MLP) 4.6e-2 RMS, DINOv2-like (SwiGLU: a product of two quantised branches, LayerScale,
+    # final LayerNorm) 1.4e-1 RMS after 3 random-init layers
+    assert rms < (8e-2 if kind == "siglip" else 2e-1) and rel(got, ref) < 0.35
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_qformer_chunk_vs_golden(dtype):
     """tdc/cambrian_arch.py:1629-1667 on one 6-frame chunk: compressed tokens within 1e-3 (fp16)."""
     W, o = load_fixture("qformer_small.npz")
