@@ -340,7 +340,8 @@ class CambrianMetaModel:
         return sd
 
     def tdc_engine(self, device=None, dtype=None, refresh=False):
-        """Build (once) the VideoEncoder from the current parameters: pads / fuses / uploads the weights."""
+        """Build (once) the VideoEncoder from the current parameters: pads / fuses / uploads the weights.
+        `config.tdc_fp8_towers = True` (not a reference key) selects e4m3 operands for the towers' qkv / fc1 GEMMs."""
         if self._tdc_encoder is None or refresh:
             cfg = {k: getattr(self.config, k) for k in dir(self.config)
                    if not k.startswith("_") and isinstance(getattr(self.config, k, None), (int, float, str, bool, list))}
@@ -349,7 +350,8 @@ class CambrianMetaModel:
             towers = self.vision_tower_aux_list
             self._tdc_encoder = VideoEncoder(self.tdc_state_dict(), cfg, dtype=dtype, device=device,
                                              siglip_heads=towers[0].heads, dino_heads=towers[1].heads,
-                                             qformer_heads=self._qformer_arch["heads"])
+                                             qformer_heads=self._qformer_arch["heads"],
+                                             fp8_towers=bool(cfg.get("tdc_fp8_towers", False)))
         return self._tdc_encoder
 
 
