@@ -249,3 +249,34 @@ def test_checkpoint_loader_roundtrip(tmp_path):
     got = lm.model.tdc_state_dict()
     for k, v in W.items():
         assert torch.equal(got[k], v), k
+
+
+def test_weight_prep_layernorm_fold_and_fp8(monkeypatch):
+    """One-time weight preparation of the optional tower paths, on the CPU: the LayerNorm fold (W diag(gamma), bias
+    beta W^T + b, c1 = row sums of the ROUNDED folded weight) reproduces LN(x) W^T + b, and the fp8 preparation keeps
+    every weight within e4m3's half-ulp of its 16-bit value with the row maximum on the largest e4m3 number."""
+    from tdc_video_amd import weights as Wt
+    g = torch.Generator().manual_seed(0)
+    D, N = 128, 192
+    W, b = torch.randn(N, D, generator=g) / D ** 0.5, torch.randn(N, generator=g)
+    gamma, beta = 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    x = torch.randn(7, D, generator=g) * 2 + 0.3
+    lin = Wt.make_lin(W, b, torch.float32, "cpu", col_scale=gamma, col_shift=beta)
+    c1 = Wt.fold_c1(lin)
+    mean, rstd = x.mean(1, keepdim=True), (x.var(1, unbiased=False, keepdim=True) + 1e-6).rsqrt()
+    got = rstd * (x @ lin.w[:N, :D].t() - mean * c1[:N]) + lin.b[:N]
+    ref = torch.nn.functional.layer_norm(x, (D,), gamma, beta, 1e-6) @ W.t() + b
+    assert (got - ref).abs().max().item() < 1e-4
+    # fp8: per-tensor scale, bytes of e4m3, K padded to whole 128-byte tiles
+    lin16 = Wt.make_lin(W, b, torch.bfloat16, "cpu")
+    l8 = Wt.to_fp8(lin16, "cpu")
+    assert l8.w.dtype == torch.uint8 and l8.w.shape == (192, 128) and l8.zeros.numel() == 192 and l8.b is lin16.b
+    deq = l8.w.view(torch.float8_e4m3fn).float() * l8.wscale
+    assert (deq - lin16.w.float()).abs().max().item() <= lin16.w.float().abs().max().item() * 2 ** -4
+    assert abs(deq.abs().max().item() - lin16.w.float().abs().max().item()) < 1e-6
+    # switches: fusion needs whole 64-column slots, fp8 whole 128-byte K tiles, and fp8 excludes the fusion
+    monkeypatch.setenv("TDC_LN_FUSE", "1")
+    assert Wt.ln_fusion_enabled(1152) and not Wt.ln_fusion_enabled(48)
+    assert Wt.fp8_enabled(1536, True) and not Wt.fp8_enabled(1152 + 64, True) and not Wt.fp8_enabled(1536, False)
+    monkeypatch.delenv("TDC_LN_FUSE")
+    assert not Wt.ln_fusion_enabled(1152)
