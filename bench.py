@@ -175,7 +175,7 @@ def main():
     ap.add_argument("--hidden", type=int, default=3584, help="LLM embed dim (Qwen2-7B)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp8"],
                     help="fp8 (BASELINE config 5): e4m3 operands for the towers' LayerNorm-fed GEMMs (qkv, fc1) through "
-                         "v_mfma_f32_16x16x32_fp8_fp8, bf16 everywhere else")
+                         "v_mfma_f32_16x16x128_f8f6f4, bf16 everywhere else")
     ap.add_argument("--px", type=int, default=384, help="SigLIP input size (DINO uses px-6: 378); 336 -> 336/336")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tower-batch", type=int, default=512)

@@ -60,7 +60,7 @@ typedef struct {
     void* x16; int ldx16; float* ln_part;
     const float* ln_stats; const float* ln_c1;
     /* in_fp8 != 0: A and W hold OCP e4m3 bytes (K % 128 == 0, lda / ldw % 16 == 0, both counted in values), accumulated by
-     * v_mfma_f32_16x16x32_fp8_fp8; `dtype` stays the 16-bit type of C / res.  The dequantisation scales ride on the
+     * v_mfma_f32_16x16x128_f8f6f4 (unit block scales); `dtype` stays the 16-bit type of C / res.  The dequantisation scales ride on the
      * LayerNorm-fold operands: ln_stats[m] = (0, s_a[m] * s_w) and ln_c1 = 0 give C = act(s_a[m] s_w acc + bias). */
     int in_fp8;
 } tdc_gemm_desc;

@@ -50,6 +50,18 @@ __device__ __forceinline__ f32x4 mma16(V8 a, V8 b, f32x4 c) {
     }
 }
 
+// ... and both 16-byte fragments of a 128-byte K tile (32 e4m3 values per lane) feed ONE v_mfma_f32_16x16x128_f8f6f4
+// (unit block scales): 32 cycles for four times the K of the 16-cycle bf16 / fp8 16x16x32 forms - twice their rate.
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+template <class V8>
+__device__ __forceinline__ f32x4 mma128_fp8(V8 a0, V8 a1, V8 b0, V8 b1, f32x4 c) {
+    const u32x4 x0 = __builtin_bit_cast(u32x4, a0), x1 = __builtin_bit_cast(u32x4, a1);
+    const u32x4 y0 = __builtin_bit_cast(u32x4, b0), y1 = __builtin_bit_cast(u32x4, b1);
+    const i32x8 a = {(int)x0[0], (int)x0[1], (int)x0[2], (int)x0[3], (int)x1[0], (int)x1[1], (int)x1[2], (int)x1[3]};
+    const i32x8 b = {(int)y0[0], (int)y0[1], (int)y0[2], (int)y0[3], (int)y1[0], (int)y1[1], (int)y1[2], (int)y1[3]};
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);
+}
+
 // Activations for GEMM epilogues.  They run once per output element inside an MFMA-bound kernel, so they are written
 // with the two quarter-rate instructions v_exp_f32 / v_rcp_f32 and a handful of FMAs instead of libm calls
 // (erff / tanhf cost 30-40 VALU instructions per element and dominated the fc1 epilogues).

@@ -384,18 +384,33 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
         const char* la = smem + cur * TILE_BYTES;
         const char* lw = smem + 2 * TILE_BYTES + cur * TILE_BYTES;
+        if constexpr (FP8) {        // both halves of the 128-byte K tile in one 16x16x128 MFMA (common.h)
+            v8 xa[2][4], xw[2][4];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            v8 xa[4], xw[4];
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                xa[i] = *(const v8*)(la + (a_off[i] ^ (ks << 6)));
-                xw[i] = *(const v8*)(lw + (w_off[i] ^ (ks << 6)));
-            }
+                for (int i = 0; i < 4; ++i) {
+                    xa[ks][i] = *(const v8*)(la + (a_off[i] ^ (ks << 6)));
+                    xw[ks][i] = *(const v8*)(lw + (w_off[i] ^ (ks << 6)));
+                }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mma16<FP8>(xw[j], xa[i], acc[i][j]);
+                for (int j = 0; j < 4; ++j) acc[i][j] = mma128_fp8(xw[0][j], xw[1][j], xa[0][i], xa[1][i], acc[i][j]);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                v8 xa[4], xw[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    xa[i] = *(const v8*)(la + (a_off[i] ^ (ks << 6)));
+                    xw[i] = *(const v8*)(lw + (w_off[i] ^ (ks << 6)));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(xw[j], xa[i], acc[i][j]);
+            }
         }
         __syncthreads();  // drains the glds of tile kt+1 (vmcnt(0)) and fences the reads of buffer `cur`
     }
@@ -728,10 +743,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #define T2_MMA(MI0, NJ0, fbx)                                                       \
     if (active) {                                                                   \
         __builtin_amdgcn_s_setprio(1);                                              \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                            \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                               \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                               \
-            acc[(MI0) + i][(NJ0) + j] = mma16<FP8>(fbx[j][ks], fa[i][ks], acc[(MI0) + i][(NJ0) + j]); \
+        if constexpr (FP8) {                                                        \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                           \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                           \
+                acc[(MI0) + i][(NJ0) + j] = mma128_fp8(fbx[j][0], fbx[j][1], fa[i][0], fa[i][1], acc[(MI0) + i][(NJ0) + j]); \
+        } else {                                                                    \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                        \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                           \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                           \
+                acc[(MI0) + i][(NJ0) + j] = mfma16(fbx[j][ks], fa[i][ks], acc[(MI0) + i][(NJ0) + j]); \
+        }                                                                           \
         __builtin_amdgcn_s_setprio(0);                                              \
     }
 

@@ -23,7 +23,7 @@ class VideoEncoder:
                  qformer_heads=12, tower_batch=64, fp8_towers=False):
         """sd: reference-named state dict without the leading 'model.'; cfg: dict of reference config keys.
         fp8_towers (BASELINE config 5): the towers' LayerNorms emit e4m3 rows with per-row scales and the qkv / fc1 GEMMs
-        run on fp8 operands (v_mfma_f32_16x16x32_fp8_fp8); everything else stays in `dtype`."""
+        run on fp8 operands (v_mfma_f32_16x16x128_f8f6f4); everything else stays in `dtype`."""
         self.cfg = dict(cfg)
         self.dtype, self.dev = dtype, torch.device(device)
         self.tower_batch = tower_batch

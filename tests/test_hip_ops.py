@@ -169,7 +169,7 @@ def test_gemm_layernorm_fusion(ops, dtype, M):
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("M", [300, 8192, 80 * 256 - 19])
 def test_gemm_fp8_operands(ops, dtype, M):
-    """A and W as OCP e4m3 bytes through v_mfma_f32_16x16x32_fp8_fp8 (all three GEMM kernels), per-row activation scale x
+    """A and W as OCP e4m3 bytes through v_mfma_f32_16x16x128_f8f6f4 (all three GEMM kernels), per-row activation scale x
     per-tensor weight scale applied through the LayerNorm-fold operands.  The reference is the SAME quantised operands
     multiplied in fp32, so the tolerance is the 16-bit output rounding, not the fp8 quantisation."""
     from tdc_video_amd import lib as L
