@@ -13,1181 +13,15 @@
 // 4 CONSECUTIVE output columns of one output row: bias / residual / store are 8- or 16-byte vector accesses.
 // Workgroup ids are remapped so that each XCD (private L2) owns a contiguous range of tiles, row-major over
 // (tile_m, tile_n): the tiles that share an activation row-panel run back to back on one L2.
-#include "common.h"
-#include "../../include/tdc_hip.h"
-#include <stdio.h>
-#include <stdlib.h>
-#include <type_traits>
 
-namespace {
+#include "gemm_impl.h"
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
-
-struct GemmArgs {
-    const void* A; const void* W; void* C; const float* bias; const void* res;
-    int lda, ldw, ldc, ldres;
-    int M, N, K;
-    int out_f32, res_f32, act;
-    RowMap am, cm, rm;
-    int tiles_m, tiles_n;
-    int debug;   // TDC_GEMM_DEBUG: 1 = skip the epilogue, 2 = direct (un-staged) epilogue - timing experiments only
-    // LayerNorm fusion (see EpiOps / slot_stats_*): producer side x16 + ln_part, consumer side ln_stats + ln_c1
-    void* x16; int ldx16; float* ln_part;
-    const float* ln_stats; const float* ln_c1;
+// e4m3-operand instantiations live in gemm_fp8.hip (a translation unit of its own: the two compile in parallel)
 #ifdef TDC_GEMM_DIAG
-    unsigned long long* stamps;   // diagnostics build only (tools/gemm_stamps.cpp): 8 x u64 per workgroup
-#endif
-};
-
-// In-kernel timeline stamps (s_memrealtime, 100 MHz) of wave 0 - compiled only into the diagnostics build
-#ifdef TDC_GEMM_DIAG
-#define TDC_STAMP(k)                                                                              \
-    if (p.stamps && threadIdx.x == 0) {                                                           \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        p.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime();               \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-    }
+static int tdc_gemm_fp8_impl(const tdc_gemm_desc*, hipStream_t) { return TDC_E_BADARG; }   // diagnostics tool: 16-bit only
 #else
-#define TDC_STAMP(k)
+int tdc_gemm_fp8_impl(const tdc_gemm_desc* d, hipStream_t st);
 #endif
-
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    // bijective "contiguous chunk per XCD" remap (cdna_hip_programming.md T1): blocks b, b+8, ... share an XCD
-    int q = nwg >> 3, r = nwg & 7, x = bid & 7;
-    int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
-    return base + (bid >> 3);
-}
-
-// ---- epilogue operands ----------------------------------------------------------------------------------------------
-// Per-column / per-row operands of a wave's sub-tile in the MFMA layout: lane (fr, g) holds, per accumulator tile (i, j),
-// row 16 i + fr and columns 16 j + 4 g .. +3.
-//   bias[j]          - the nn.Linear bias (LayerNorm fusion: beta . W^T + b);
-//   c1[j], mean[i], rstd[i] (FOLD) - LayerNorm fused into the consumer GEMM: A holds the RAW 16-bit rows x, W the
-//                      gamma-folded weight W' = W diag(gamma); LN(x) W^T + b == rstd (x W'^T - mean c1) + bias with
-//                      c1[n] = sum_k W'[n, k]; (mean, rstd) of row m come from ln_stats [M, 2] (tdc_ln_finalize).
-// In the persistent kernel these values are already in registers, one column / row per lane (EpiLane, loaded one tile
-// ahead so that no vector-memory load - whose in-order vmcnt wait would also wait for the next tile's staged operands -
-// sits at the start of the epilogue) and are gathered with ds_bpermute; the other kernels load them here.
-struct EpiLane {
-    float bias, c1;        // column nbase + lane
-    float mean0, rstd0;    // row mbase + lane
-    float mean1, rstd1;    // row mbase + 64 + lane
-};
-
-__device__ __forceinline__ float lane_get(float v, int src_lane) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane * 4, __builtin_bit_cast(int, v)));
-}
-
-template <int MI, int NJ, bool LANE, bool FOLD>
-struct EpiOps {
-    f32x4 bias[NJ], c1[NJ];
-    float mean[MI], rstd[MI];
-    __device__ __forceinline__ void load(const GemmArgs& p, int mbase, int nbase, int fr, int g, const EpiLane& el) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            if (LANE) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    bias[j][e] = lane_get(el.bias, j * 16 + g * 4 + e);
-                    if (FOLD) c1[j][e] = lane_get(el.c1, j * 16 + g * 4 + e);
-                }
-            } else {
-                const int n = nbase + j * 16 + g * 4;
-                bias[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (FOLD) c1[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (n < p.N) {
-                    if (p.bias) bias[j] = *(const f32x4*)(p.bias + n);
-                    if (FOLD) c1[j] = *(const f32x4*)(p.ln_c1 + n);
-                }
-            }
-        }
-        if (FOLD) {
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                if (LANE) {
-                    const int r = (i & 3) * 16 + fr;
-                    mean[i] = lane_get(i < 4 ? el.mean0 : el.mean1, r);
-                    rstd[i] = lane_get(i < 4 ? el.rstd0 : el.rstd1, r);
-                } else {
-                    int m = mbase + i * 16 + fr;
-                    if (m > p.M - 1) m = p.M - 1;
-                    const float2 st = *(const float2*)(p.ln_stats + 2 * (long long)m);
-                    mean[i] = st.x; rstd[i] = st.y;
-                }
-            }
-        }
-    }
-    // the linear output of accumulator tile (i, j).  FOLD: two explicit fmas per element - the same instruction sequence
-    // in every kernel and layout (a row must not depend on which kernel computed it)
-    __device__ __forceinline__ f32x4 lin(f32x4 acc, int i, int j) const {
-        if (!FOLD) return acc + bias[j];
-        f32x4 r;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            r[e] = __builtin_fmaf(rstd[i], __builtin_fmaf(-mean[i], c1[j][e], acc[e]), bias[j][e]);
-        return r;
-    }
-};
-
-// ---- LayerNorm fusion, producer side: (mean, M2) of one row x 64-column slot --------------------------------------------
-// The fp32 residual-stream GEMMs (out-projection, fc2) also write the updated row as 16-bit (x16, the next GEMM's A
-// operand) and, per row and 64-column slot, the slot's mean and sum of squared deviations; tdc_ln_finalize combines the
-// N/64 slots of a row (Chan) into (mean, rstd).  The two layouts below run the SAME balanced tree over the 16 four-column
-// groups c = 0..15 of a slot (pairs c^1, c^2, c^4, c^8 in that order, no fp contraction), so the partials - like every
-// other output - are bit-identical whichever kernel computes a row.
-#pragma clang fp contract(off)
-// staged layout: the 16 lanes of a row segment hold groups c = lane & 15 (DPP exchanges inside the 16-lane row)
-__device__ __forceinline__ float row16_xch(float v, int level) {
-    const int x = __builtin_bit_cast(int, v);
-    int r;
-    if (level == 0) r = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
-    else if (level == 1) r = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
-    else if (level == 2) r = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false);  // row_half_mirror
-    else r = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false);                  // row_mirror
-    return __builtin_bit_cast(float, r);
-}
-__device__ __forceinline__ void slot_stats_row16(f32x4 v, float& mean, float& m2) {
-    float s = (v[0] + v[1]) + (v[2] + v[3]);
-#pragma unroll
-    for (int l = 0; l < 4; ++l) s = s + row16_xch(s, l);
-    mean = s * 0.015625f;
-    const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
-    float q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-#pragma unroll
-    for (int l = 0; l < 4; ++l) q = q + row16_xch(q, l);
-    m2 = q;
-}
-// MFMA layout: group c = 4 j + g: g across the lanes l ^ 16, l ^ 32, j across the four accumulator tiles of the row
-__device__ __forceinline__ void slot_stats_mfma(const f32x4 (&v)[4], float& mean, float& m2) {
-    float s[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        s[j] = (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
-        s[j] = s[j] + __shfl_xor(s[j], 16);
-        s[j] = s[j] + __shfl_xor(s[j], 32);
-    }
-    mean = ((s[0] + s[1]) + (s[2] + s[3])) * 0.015625f;
-    float q[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float d0 = v[j][0] - mean, d1 = v[j][1] - mean, d2 = v[j][2] - mean, d3 = v[j][3] - mean;
-        q[j] = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-        q[j] = q[j] + __shfl_xor(q[j], 16);
-        q[j] = q[j] + __shfl_xor(q[j], 32);
-    }
-    m2 = (q[0] + q[1]) + (q[2] + q[3]);
-}
-#pragma clang fp contract(fast)
-
-// ---- epilogue, MFMA layout (128^2 kernel; fallback of the 256^2 kernels) ---------------------------------------------------
-// Each lane holds, per (i, j) accumulator tile, 4 consecutive output columns n..n+3 of ONE output row m.  The epilogue
-// is specialised at compile time on (activation, residual kind, output type, LayerNorm fusion): the run-time flags select
-// one of the branch-free instantiations once per kernel.
-template <class T, int ACT, int RES, bool OUTF32>
-__device__ __forceinline__ void epi_store(const GemmArgs& p, f32x4 v, long long crow, long long rrow, int n) {
-    if (ACT == TDC_ACT_GELU_ERF) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-    } else if (ACT == TDC_ACT_GELU_TANH) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
-    } else if (ACT == TDC_ACT_SWIGLU) {
-        // columns are interleaved (x1_j, x2_j): two outputs per lane at column n/2
-        const float o0 = silu(v[0]) * v[1], o1 = silu(v[2]) * v[3];
-        const int nc = n >> 1;
-        if (OUTF32) {
-            float* c = (float*)p.C + crow * p.ldc + nc;
-            c[0] = o0; c[1] = o1;
-        } else {
-            typedef __attribute__((ext_vector_type(2))) T v2;
-            v2 o; o[0] = (T)o0; o[1] = (T)o1;
-            *(v2*)((T*)p.C + crow * p.ldc + nc) = o;
-        }
-        return;
-    }
-    if (RES == 1) {
-        v += *(const f32x4*)((const float*)p.res + rrow * p.ldres + n);
-    } else if (RES == 2) {
-        typename VecOf<T>::v4 r = *(const typename VecOf<T>::v4*)((const T*)p.res + rrow * p.ldres + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
-    }
-    if (OUTF32) {
-        *(f32x4*)((float*)p.C + crow * p.ldc + n) = v;
-    } else {
-        typename VecOf<T>::v4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (T)v[e];
-        *(typename VecOf<T>::v4*)((T*)p.C + crow * p.ldc + n) = o;
-    }
-}
-
-template <class T, int MI, int NJ, int ACT, int RES, bool OUTF32, bool LB, bool FOLD>
-__device__ __forceinline__ void epi_tile(const GemmArgs& p, f32x4 (&acc)[MI][NJ], int mbase, int nbase, int fr,
-                                         int g, const EpiLane& el) {
-    EpiOps<MI, NJ, LB, FOLD> ops;
-    ops.load(p, mbase, nbase, fr, g, el);
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = mbase + i * 16 + fr;
-        if (m < p.M) {
-            const long long crow = p.cm(m);
-            const long long rrow = RES ? p.rm(m) : 0;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int n = nbase + j * 16 + g * 4;
-                if (n < p.N) epi_store<T, ACT, RES, OUTF32>(p, ops.lin(acc[i][j], i, j), crow, rrow, n);
-            }
-        }
-    }
-}
-
-// fp32 residual stream update + 16-bit copy + per-slot LayerNorm partials (N % 64 == 0, identity c_map / r_map)
-template <class T, int MI, bool LB>
-__device__ __forceinline__ void epi_tile_emit(const GemmArgs& p, f32x4 (&acc)[MI][4], int mbase, int nbase, int fr,
-                                              int g, const EpiLane& el) {
-    typedef typename VecOf<T>::v4 v4;
-    if (nbase >= p.N) return;                       // wave-uniform
-    EpiOps<MI, 4, LB, false> ops;
-    ops.load(p, mbase, nbase, fr, g, el);
-    const int slot = nbase >> 6;      // partials are slot-major: ln_part[slot][M][2]
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = mbase + i * 16 + fr;
-        const int mc = m < p.M ? m : p.M - 1;       // clamped rows compute (the exchanges need every lane), never store
-        f32x4 v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = nbase + j * 16 + g * 4;
-            v[j] = ops.lin(acc[i][j], i, j) + *(const f32x4*)((const float*)p.res + (long long)mc * p.ldres + n);
-        }
-        float mean, m2;
-        slot_stats_mfma(v, mean, m2);
-        if (m < p.M) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = nbase + j * 16 + g * 4;
-                *(f32x4*)((float*)p.C + (long long)m * p.ldc + n) = v[j];
-                v4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (T)v[j][e];
-                *(v4*)((T*)p.x16 + (long long)m * p.ldx16 + n) = o;
-            }
-            if (g == 0) *(float2*)(p.ln_part + 2 * ((long long)slot * p.M + m)) = make_float2(mean, m2);
-        }
-    }
-}
-
-template <class T, int MI, int NJ, bool LB, bool FOLD>
-__device__ __forceinline__ void epilogue_f(const GemmArgs& p, f32x4 (&acc)[MI][NJ], int mbase, int nbase, int fr, int g,
-                                           const EpiLane& el) {
-    const int res = p.res ? (p.res_f32 ? 1 : 2) : 0;
-    if (p.act == TDC_ACT_GELU_ERF) epi_tile<T, MI, NJ, TDC_ACT_GELU_ERF, 0, false, LB, FOLD>(p, acc, mbase, nbase, fr, g, el);
-    else if (p.act == TDC_ACT_GELU_TANH) epi_tile<T, MI, NJ, TDC_ACT_GELU_TANH, 0, false, LB, FOLD>(p, acc, mbase, nbase, fr, g, el);
-    else if (p.act == TDC_ACT_SWIGLU) epi_tile<T, MI, NJ, TDC_ACT_SWIGLU, 0, false, LB, FOLD>(p, acc, mbase, nbase, fr, g, el);
-    else if (!p.out_f32 && res == 0) epi_tile<T, MI, NJ, 0, 0, false, LB, FOLD>(p, acc, mbase, nbase, fr, g, el);
-    else if (FOLD) return;                          // (host-checked: the fold only exists for 16-bit outputs without residual)
-    else if (p.out_f32) {
-        if (res == 1) epi_tile<T, MI, NJ, 0, 1, true, LB, false>(p, acc, mbase, nbase, fr, g, el);
-        else if (res == 2) epi_tile<T, MI, NJ, 0, 2, true, LB, false>(p, acc, mbase, nbase, fr, g, el);
-        else epi_tile<T, MI, NJ, 0, 0, true, LB, false>(p, acc, mbase, nbase, fr, g, el);
-    } else {
-        if (res == 1) epi_tile<T, MI, NJ, 0, 1, false, LB, false>(p, acc, mbase, nbase, fr, g, el);
-        else epi_tile<T, MI, NJ, 0, 2, false, LB, false>(p, acc, mbase, nbase, fr, g, el);
-    }
-}
-
-template <class T, int MI, int NJ, bool LB = false>
-__device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[MI][NJ], int mbase, int nbase, int fr, int g,
-                                         const EpiLane& el = EpiLane()) {
-    if (NJ == 4 && p.x16) { epi_tile_emit<T, MI, LB>(p, (f32x4 (&)[MI][4])acc, mbase, nbase, fr, g, el); return; }
-    if (!LB && p.ln_stats) epilogue_f<T, MI, NJ, LB, true>(p, acc, mbase, nbase, fr, g, el);   // lane-held: LNF kernel
-    else epilogue_f<T, MI, NJ, LB, false>(p, acc, mbase, nbase, fr, g, el);
-}
-
-// tile id -> (tile_m, tile_n), "grouped" order: ids walk GROUP_M tile rows column by column before moving to the next
-// group of rows.  The 32 workgroups that one XCD runs concurrently (consecutive ids after xcd_remap) then cover an
-// 8 x 4 patch of tiles: 8 activation panels + 4 weight panels stream through that XCD's L2 instead of 1 + 32
-// (PMC, N = 8192: 9.6x the algorithmic bytes crossed the fabric with the plain row-major order).
-constexpr int GROUP_M = 8;
-__device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
-    const int per_group = GROUP_M * tiles_n;
-    const int grp = id / per_group, within = id - grp * per_group;
-    const int first = grp * GROUP_M;
-    const int rows = (tiles_m - first < GROUP_M) ? tiles_m - first : GROUP_M;
-    tn = within / rows;
-    tm = first + (within - tn * rows);
-}
-
-// FP8: A and W hold e4m3 bytes; all addressing below stays in 2-byte units (the host passes K / 2, lda / 2, ldw / 2), only
-// the MFMA differs (common.h: mma16).  T remains the 16-bit output / residual type.
-template <class T, bool FP8>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
-    typedef typename VecOf<T>::v8 v8;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // smem: A[2][16K] | W[2][16K]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int id = xcd_remap(blockIdx.x, nwg);
-    int tm, tn;
-    tile_coords(id, p.tiles_m, p.tiles_n, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    // ---- staging addresses: wave w issues 4 glds for A and 4 for W per K tile; instruction i covers rows 8i..8i+7
-    const int srow = lane >> 3;                        // row within the 8-row group (== row & 7)
-    const int schunk = (lane & 7) ^ srow;              // logical 16-B chunk loaded into physical chunk (lane & 7)
-    const char* a_src[4];
-    const char* w_src[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        int r = (wave * 4 + j) * 8 + srow;
-        int am = m0 + r; if (am > p.M - 1) am = p.M - 1;
-        int wn = n0 + r; if (wn > p.N - 1) wn = p.N - 1;
-        a_src[j] = (const char*)p.A + (p.am(am) * (long long)p.lda + schunk * 8) * 2;
-        w_src[j] = (const char*)p.W + ((long long)wn * p.ldw + schunk * 8) * 2;
-    }
-    auto stage = [&](int buf, int kt) {
-        const long long koff = (long long)kt * BK * 2;
-        char* la = smem + buf * TILE_BYTES + wave * 4 * 1024;
-        char* lw = smem + 2 * TILE_BYTES + buf * TILE_BYTES + wave * 4 * 1024;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[j] + koff), LDS_PTR(la + j * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(w_src[j] + koff), LDS_PTR(lw + j * 1024), 16, 0, 0);
-        }
-    };
-
-    // ---- fragment read addresses (bytes within a tile): row r, logical chunk c -> r*128 + ((c ^ (r&7)) * 16)
-    const int wm = wave >> 1, wn_ = wave & 1;
-    const int fr = lane & 15, g = lane >> 4;
-    int a_off[4], w_off[4];  // byte offset of (row, chunk g) for k-step 0; k-step 1 flips chunk bit 2
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int ra = wm * 64 + i * 16 + fr;
-        int rw = wn_ * 64 + i * 16 + fr;
-        a_off[i] = ra * 128 + ((g ^ (ra & 7)) << 4);
-        w_off[i] = rw * 128 + ((g ^ (rw & 7)) << 4);
-    }
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nk = p.K / BK;
-    stage(0, 0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-        const char* la = smem + cur * TILE_BYTES;
-        const char* lw = smem + 2 * TILE_BYTES + cur * TILE_BYTES;
-        if constexpr (FP8) {        // both halves of the 128-byte K tile in one 16x16x128 MFMA (common.h)
-            v8 xa[2][4], xw[2][4];
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    xa[ks][i] = *(const v8*)(la + (a_off[i] ^ (ks << 6)));
-                    xw[ks][i] = *(const v8*)(lw + (w_off[i] ^ (ks << 6)));
-                }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mma128_fp8(xw[0][j], xw[1][j], xa[0][i], xa[1][i], acc[i][j]);
-        } else {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                v8 xa[4], xw[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    xa[i] = *(const v8*)(la + (a_off[i] ^ (ks << 6)));
-                    xw[i] = *(const v8*)(lw + (w_off[i] ^ (ks << 6)));
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(xw[j], xa[i], acc[i][j]);
-            }
-        }
-        __syncthreads();  // drains the glds of tile kt+1 (vmcnt(0)) and fences the reads of buffer `cur`
-    }
-
-    // ---- epilogue: lane holds C[m = m0 + wm*64 + 16 i + fr][n = n0 + wn*64 + 16 j + 4g .. +3]
-    epilogue<T, 4, 4>(p, acc, m0 + wm * 64, n0 + wn_ * 64, fr, g);
-}
-
-// ---- LDS-staged epilogue of the 256^2 kernels -------------------------------------------------------------------------
-// Row-per-lane stores straight from the MFMA layout touch 16 cache lines with 8 B each per instruction and are
-// store-ISSUE bound (~7 B/clk/CU, cdna_hip_programming.md T21): the 128 KiB C tile cost ~9 us per workgroup, 25 % of a
-// K=1152 GEMM.  Instead every wave transposes its 128x64 sub-tile through LDS (its own 16 KiB of the idle pipeline
-// buffers; 4 KiB beside the live pipeline in the persistent kernel: ROWS rows per pass) and stores whole rows: one
-// instruction = 8 rows x 128 B (16-bit out) or 4 rows x 256 B (fp32 out), 16 B per lane.  Bias / LayerNorm fold /
-// activation run before staging (MFMA layout); the fp32 residual add runs after it, on full 256-B row segments.  XOR
-// swizzle of the 16-B chunk with the row keeps both sides (nearly) conflict-free.
-template <class T, int ACT, int RES, int ROWS, bool LB, bool FOLD>
-__device__ __forceinline__ void epi_staged16(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase, int nbase,
-                                             int lane, const EpiLane& el) {
-    // ROWS = rows of the wave's 128x64 sub-tile staged per pass (128-byte rows): 128 (16 KiB region) or 32 (4 KiB)
-    typedef typename VecOf<T>::v4 v4;
-    typedef typename VecOf<T>::v8 v8;
-    const int fr = lane & 15, g = lane >> 4;
-    EpiOps<8, 4, LB, FOLD> ops;
-    ops.load(p, mbase, nbase, fr, g, el);
-#pragma unroll
-    for (int pass = 0; pass < 128 / ROWS; ++pass) {
-#pragma unroll
-        for (int ii = 0; ii < ROWS / 16; ++ii) {
-            const int i = pass * (ROWS / 16) + ii;
-            const int r = ii * 16 + fr;                 // row within the staging region
-            const int m = mbase + i * 16 + fr;
-            long long rrow = 0;
-            if (RES == 2) rrow = p.rm(m < p.M ? m : p.M - 1);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f32x4 v = ops.lin(acc[i][j], i, j);
-                if (ACT == TDC_ACT_GELU_ERF) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-                } else if (ACT == TDC_ACT_GELU_TANH) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
-                }
-                if (RES == 2) {   // 16-bit residual: add before the single rounding to T
-                    const int n = nbase + j * 16 + g * 4;
-                    if (n < p.N) {
-                        v4 rr = *(const v4*)((const T*)p.res + rrow * p.ldres + n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
-                    }
-                }
-                v4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (T)v[e];
-                const int chunk = (j * 2 + (g >> 1)) ^ (r & 7);
-                *(v4*)(region + r * 128 + chunk * 16 + (g & 1) * 8) = o;
-            }
-        }
-        // same wave, in-order LDS queue: the reads below observe the writes above (and the next pass's writes follow
-        // these reads)
-#pragma unroll
-        for (int q = 0; q < ROWS / 8; ++q) {
-            const int r = q * 8 + (lane >> 3), k = lane & 7;
-            const v8 val = *(const v8*)(region + r * 128 + ((k ^ (r & 7)) << 4));
-            const int m = mbase + pass * ROWS + r, n = nbase + k * 8;
-            if (m < p.M && n < p.N) __builtin_nontemporal_store(val, (v8*)((T*)p.C + p.cm(m) * p.ldc + n));
-        }
-    }
-}
-
-// SwiGLU: columns are interleaved (x1_j, x2_j); each lane produces 2 outputs per accumulator tile, the wave's 128x64
-// sub-tile becomes 128 rows x 32 outputs (64-byte rows, 8 KiB).  Staging turns 32 four-byte stores per lane (16 rows
-// x 16 B per instruction) into 8 sixteen-byte stores (16 rows x 64 B per instruction).
-template <class T, int ROWS, bool LB, bool FOLD>
-__device__ __forceinline__ void epi_staged_swiglu(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase,
-                                                  int nbase, int lane, const EpiLane& el) {
-    typedef __attribute__((ext_vector_type(2))) T v2;
-    typedef typename VecOf<T>::v8 v8;
-    const int fr = lane & 15, g = lane >> 4;
-    EpiOps<8, 4, LB, FOLD> ops;
-    ops.load(p, mbase, nbase, fr, g, el);
-#pragma unroll
-    for (int pass = 0; pass < 128 / ROWS; ++pass) {
-#pragma unroll
-        for (int ii = 0; ii < ROWS / 16; ++ii) {
-            const int i = pass * (ROWS / 16) + ii;
-            const int r = ii * 16 + fr;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 v = ops.lin(acc[i][j], i, j);
-                v2 o;
-                o[0] = (T)(silu(v[0]) * v[1]);
-                o[1] = (T)(silu(v[2]) * v[3]);
-                // output column within the wave's 32: j*8 + 2g -> 16-B chunk j (4 per row), swizzled with the row
-                const int chunk = j ^ ((r >> 2) & 3);
-                *(v2*)(region + r * 64 + chunk * 16 + g * 4) = o;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < ROWS / 16; ++q) {
-            const int r = q * 16 + (lane >> 2), k = lane & 3;
-            const v8 val = *(const v8*)(region + r * 64 + ((k ^ ((r >> 2) & 3)) << 4));
-            const int m = mbase + pass * ROWS + r, nc = (nbase >> 1) + k * 8;
-            if (m < p.M && 2 * nc < p.N) __builtin_nontemporal_store(val, (v8*)((T*)p.C + p.cm(m) * p.ldc + nc));
-        }
-    }
-}
-
-// fp32 output (+ fp32 residual).  EMIT (LayerNorm fusion, producer side): the updated row also goes out as 16-bit
-// (x16) together with the per-slot (mean, M2) partials - identity row maps, N % 64 == 0.
-template <class T, int RES, int ROWS, bool LB, bool EMIT>
-__device__ __forceinline__ void epi_staged32(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase, int nbase,
-                                             int lane, const EpiLane& el) {
-    // ROWS = rows staged per pass (256-byte fp32 rows): 64 (16 KiB region) or 16 (4 KiB)
-    typedef typename VecOf<T>::v4 v4;
-    const int fr = lane & 15, g = lane >> 4;
-    EpiOps<8, 4, LB, false> ops;
-    ops.load(p, mbase, nbase, fr, g, el);
-    constexpr int NPASS = 128 / ROWS, QP = ROWS / 4;      // QP read-back instructions (4 rows x 256 B each) per pass
-    // The residual loads run as a ring of RING loads ahead of the read-back, independent of the staging passes (they
-    // touch no LDS); they come from clamped (always valid) addresses so that no branch - and no vmcnt(0) - separates them.
-    constexpr int RING = 8;
-    f32x4 rr[RING];
-    auto load_res = [&](int u) {                           // unit u = rows 4u .. 4u+3 of the wave's sub-tile
-        const int k = lane & 15;
-        int m = mbase + u * 4 + (lane >> 4), n = nbase + k * 4;
-        if (m > p.M - 1) m = p.M - 1;
-        if (n > p.N - 4) n = p.N - 4;
-        return *(const f32x4*)((const float*)p.res + p.rm(m) * p.ldres + n);
-    };
-    if (RES == 1) {
-#pragma unroll
-        for (int u = 0; u < RING; ++u) rr[u] = load_res(u);
-    }
-    const int slot = nbase >> 6;      // partials are slot-major: ln_part[slot][M][2]
-#pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass) {
-#pragma unroll
-        for (int ii = 0; ii < ROWS / 16; ++ii) {
-            const int r = ii * 16 + fr;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int chunk = (j * 4 + g) ^ (r & 15);
-                const int i = pass * (ROWS / 16) + ii;
-                *(f32x4*)(region + r * 256 + chunk * 16) = ops.lin(acc[i][j], i, j);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < QP; ++q) {
-            const int u = pass * QP + q;
-            const int r = q * 4 + (lane >> 4), k = lane & 15;
-            f32x4 val = *(const f32x4*)(region + r * 256 + ((k ^ (r & 15)) << 4));
-            const int m = mbase + pass * ROWS + r, n = nbase + k * 4;
-            if (RES == 1) {
-                val += rr[u % RING];
-                if (u + RING < 32) rr[u % RING] = load_res(u + RING);
-            }
-            if (m < p.M && n < p.N) __builtin_nontemporal_store(val, (f32x4*)((float*)p.C + p.cm(m) * p.ldc + n));
-            if (EMIT) {
-                float mean, m2;
-                slot_stats_row16(val, mean, m2);          // every lane takes part (rows beyond M: clamped duplicates)
-                if (m < p.M) {
-                    v4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (T)val[e];
-                    *(v4*)((T*)p.x16 + (long long)m * p.ldx16 + n) = o;
-                    if (k == 0) *(float2*)(p.ln_part + 2 * ((long long)slot * p.M + m)) = make_float2(mean, m2);
-                }
-            }
-        }
-    }
-}
-
-// returns false when this (act, res, out) combination / alignment has no staged variant.  SMALL: 4 KiB staging region
-// per wave (the persistent kernel stages beside the live pipeline buffers, lane-held operands), otherwise 16 KiB.
-template <class T, bool SMALL, bool FOLD>
-__device__ __forceinline__ bool epilogue_staged_f(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase,
-                                                  int nbase, int lane, const EpiLane& el) {
-    const int res = p.res ? (p.res_f32 ? 1 : 2) : 0;
-    constexpr int R16 = SMALL ? 32 : 128, RSW = SMALL ? 64 : 128;
-    if (p.out_f32 || res == 1 || (p.ldc & 7) || ((uintptr_t)p.C & 15)) return false;
-    if (p.act == TDC_ACT_SWIGLU) {
-        if (p.N & 15) return false;
-        epi_staged_swiglu<T, RSW, SMALL, FOLD>(p, acc, region, mbase, nbase, lane, el);
-        return true;
-    }
-    if (p.N & 7) return false;
-    if (p.act == TDC_ACT_GELU_ERF) epi_staged16<T, TDC_ACT_GELU_ERF, 0, R16, SMALL, FOLD>(p, acc, region, mbase, nbase, lane, el);
-    else if (p.act == TDC_ACT_GELU_TANH) epi_staged16<T, TDC_ACT_GELU_TANH, 0, R16, SMALL, FOLD>(p, acc, region, mbase, nbase, lane, el);
-    else if (res == 2) { if (FOLD) return false; epi_staged16<T, 0, 2, R16, SMALL, false>(p, acc, region, mbase, nbase, lane, el); }
-    else epi_staged16<T, 0, 0, R16, SMALL, FOLD>(p, acc, region, mbase, nbase, lane, el);
-    return true;
-}
-
-template <class T, bool SMALL>
-__device__ __forceinline__ bool epilogue_staged(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase,
-                                                int nbase, int lane, const EpiLane& el = EpiLane()) {
-    constexpr int R32 = SMALL ? 16 : 64;
-    if (p.out_f32) {
-        const int res = p.res ? (p.res_f32 ? 1 : 2) : 0;
-        if (p.act != TDC_ACT_NONE || res == 2) return false;
-        if (p.x16) epi_staged32<T, 1, R32, SMALL, true>(p, acc, region, mbase, nbase, lane, el);
-        else if (res == 1) epi_staged32<T, 1, R32, SMALL, false>(p, acc, region, mbase, nbase, lane, el);
-        else epi_staged32<T, 0, R32, SMALL, false>(p, acc, region, mbase, nbase, lane, el);
-        return true;
-    }
-    if (!SMALL && p.ln_stats) return epilogue_staged_f<T, SMALL, true>(p, acc, region, mbase, nbase, lane, el);
-    return epilogue_staged_f<T, SMALL, false>(p, acc, region, mbase, nbase, lane, el);
-}
-
-
-// ======================================================================================================================
-// 256x256x64 tile, 8 waves (2 M x 4 N, 128x64 per wave), 128 KiB LDS, "8-phase" schedule (cdna_hip_programming.md
-// T3+T4): every K tile is 4 phases of 16 MFMAs (one 64x32 quadrant of the wave's tile x K=64); each phase stages ONE
-// 16-KiB half-tile with global_load_lds, and the loads stay in flight ACROSS the raw s_barriers: a counted
-// s_waitcnt vmcnt(6) once per K tile (3 half-tiles in flight), never vmcnt(0) in the steady state.
-//
-// LDS: buf[2] x {A-half0, A-half1, W-half0, W-half1} x 16 KiB.  Half h of A holds rows {wm*128 + h*64 + 0..63} of both
-// wave rows wm, half h of W the columns {wn*64 + h*32 + 0..31} of all four wave columns, so quadrant (a_h, b_h') of
-// every wave needs exactly one A half and one W half.  Quadrant order (a0,b0) (a0,b1) (a1,b1) (a1,b0): one new operand
-// sub-block per phase, b0 stays in registers.  Staging order A0 B0 B1 A1; tile t+2's A0/B0/B1 are issued during tile
-// t's phases 2/3/4 into the regions tile t has finished reading one phase earlier (all waves have passed a barrier
-// after their lgkmcnt-retired reads), tile t+1's A1 during phase 1.
-constexpr int T2_HALF = 128 * 64 * 2;         // 16 KiB
-constexpr int T2_BUF = 4 * T2_HALF;           // A0 A1 W0 W1
-constexpr int T2_LDS = 2 * T2_BUF;            // 128 KiB
-
-#define T2_EPI_BARRIER() __builtin_amdgcn_s_barrier()
-template <class T, bool FP8>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
-    typedef typename VecOf<T>::v8 v8;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int id = xcd_remap(blockIdx.x, nwg);
-    int tm, tn;
-    tile_coords(id, p.tiles_m, p.tiles_n, tm, tn);
-    const int m0 = tm * 256, n0 = tn * 256;
-#ifdef TDC_GEMM_DIAG
-    if (p.stamps && threadIdx.x == 0) {
-        p.stamps[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_ID
-        p.stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg((3 << 11) | 20);     // XCC_ID
-    }
-#endif
-    TDC_STAMP(0);
-
-    // ---- staging sources: per half 2 glds per thread; instruction (wave*2 + j) covers half rows 8*(wave*2+j) .. +7
-    const int srow = lane >> 3;
-    const int schunk = (lane & 7) ^ srow;
-    const char* a_src[2][2];
-    const char* w_src[2][2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = (wave * 2 + j) * 8 + srow;                       // row within the half (0..127)
-            int am = m0 + (r >> 6) * 128 + h * 64 + (r & 63);
-            int wn = n0 + (r >> 5) * 64 + h * 32 + (r & 31);
-            if (am > p.M - 1) am = p.M - 1;
-            if (wn > p.N - 1) wn = p.N - 1;
-            a_src[h][j] = (const char*)p.A + (p.am(am) * (long long)p.lda + schunk * 8) * 2;
-            w_src[h][j] = (const char*)p.W + ((long long)wn * p.ldw + schunk * 8) * 2;
-        }
-    const int lds_stage = wave * 2 * 1024;
-    auto stage_a = [&](int buf, int h, int kt) {
-        char* dst = smem + buf * T2_BUF + h * T2_HALF + lds_stage;
-        const long long koff = (long long)kt * 128;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[h][0] + koff), LDS_PTR(dst), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[h][1] + koff), LDS_PTR(dst + 1024), 16, 0, 0);
-    };
-    auto stage_w = [&](int buf, int h, int kt) {
-        char* dst = smem + buf * T2_BUF + (2 + h) * T2_HALF + lds_stage;
-        const long long koff = (long long)kt * 128;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(w_src[h][0] + koff), LDS_PTR(dst), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(GLB_PTR(w_src[h][1] + koff), LDS_PTR(dst + 1024), 16, 0, 0);
-    };
-
-    // ---- fragment read offsets inside a half
-    // wave -> (row, column) of the 2 x 4 wave grid: the two waves of a SIMD (w and w+4) take wave columns c and c+2, so
-    // in a tile whose upper half of the columns lies beyond N (N = 1152: the 5th column tile) every SIMD keeps exactly one
-    // working wave and the idle partner's MFMA slots are not wasted
-    const int wm = (wave >> 1) & 1, wn_ = (wave & 1) | ((wave >> 2) << 1);
-    const bool wave_active = n0 + wn_ * 64 < p.N;   // wave-uniform: this wave owns at least one valid column
-    const int fr = lane & 15, g = lane >> 4;
-    int a_off[4], w_off[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = wm * 64 + i * 16 + fr;
-        a_off[i] = r * 128 + ((g ^ (r & 7)) << 4);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = wn_ * 32 + j * 16 + fr;
-        w_off[j] = r * 128 + ((g ^ (r & 7)) << 4);
-    }
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    v8 fa[4][2], fb0[2][2], fb1[2][2];
-
-    const int nk = p.K / 64;
-#define T2_BARRIER() __builtin_amdgcn_s_barrier()
-    // end of a load segment: retire this wave's LDS reads BEFORE the barrier (so that a later stage by any wave, incl.
-    // the other, staggered, wave group, can never overwrite bytes still being read), then pin the MFMA cluster below it
-#define T2_END_LOADS()                                          \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          \
-    __builtin_amdgcn_s_barrier();                               \
-    __builtin_amdgcn_sched_barrier(0)
-#define T2_LOAD_A(buf, h)                                                          \
-    if (active) {                                                                   \
-        const char* base = smem + (buf) * T2_BUF + (h) * T2_HALF;                   \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                             \
-            fa[i][0] = *(const v8*)(base + a_off[i]);                               \
-            fa[i][1] = *(const v8*)(base + (a_off[i] ^ 64));                        \
-        }                                                                           \
-    }
-#define T2_LOAD_B(dst, buf, h)                                                      \
-    if (active) {                                                                   \
-        const char* base = smem + (buf) * T2_BUF + (2 + (h)) * T2_HALF;             \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                             \
-            dst[j][0] = *(const v8*)(base + w_off[j]);                              \
-            dst[j][1] = *(const v8*)(base + (w_off[j] ^ 64));                       \
-        }                                                                           \
-    }
-#define T2_MMA(MI0, NJ0, fbx)                                                       \
-    if (active) {                                                                   \
-        __builtin_amdgcn_s_setprio(1);                                              \
-        if constexpr (FP8) {                                                        \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                           \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j)                           \
-                acc[(MI0) + i][(NJ0) + j] = mma128_fp8(fbx[j][0], fbx[j][1], fa[i][0], fa[i][1], acc[(MI0) + i][(NJ0) + j]); \
-        } else {                                                                    \
-            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                        \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                           \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j)                           \
-                acc[(MI0) + i][(NJ0) + j] = mfma16(fbx[j][ks], fa[i][ks], acc[(MI0) + i][(NJ0) + j]); \
-        }                                                                           \
-        __builtin_amdgcn_s_setprio(0);                                              \
-    }
-
-    // The pipeline is instantiated twice: the working form, and a form for waves without a valid column that only stages
-    // and keeps the barriers (a run-time branch around the MFMA clusters inside ONE loop costs the working form ~5 %).
-    auto pipeline = [&](auto active_c) {
-    constexpr bool active = decltype(active_c)::value;
-    // ---- prologue: tile 0 complete + tile 1's A0 B0 B1
-    stage_a(0, 0, 0); stage_w(0, 0, 0); stage_w(0, 1, 0); stage_a(0, 1, 0);
-    if (nk > 1) {
-        stage_a(1, 0, 1); stage_w(1, 0, 1); stage_w(1, 1, 1);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    T2_BARRIER();
-    TDC_STAMP(1);
-    // stagger: waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in its MFMA cluster while its
-    // partner is in its LDS-read / staging segment (MI355X_MICROARCH.md "Two waves per SIMD")
-    if (wave >= 4) T2_BARRIER();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1, nxt = cur ^ 1;
-        // ---- phase 1: quadrant (a0, b0)
-        T2_LOAD_B(fb0, cur, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        T2_LOAD_A(cur, 0);
-        if (kt + 1 < nk) stage_a(nxt, 1, kt + 1);
-        T2_END_LOADS();
-        T2_MMA(0, 0, fb0);
-        T2_BARRIER();
-        // ---- phase 2: quadrant (a0, b1)
-        T2_LOAD_B(fb1, cur, 1);
-        if (kt + 2 < nk) stage_a(cur, 0, kt + 2);
-        T2_END_LOADS();
-        T2_MMA(0, 2, fb1);
-        T2_BARRIER();
-        // ---- phase 3: quadrant (a1, b1)
-        T2_LOAD_A(cur, 1);
-        if (kt + 2 < nk) stage_w(cur, 0, kt + 2);
-        T2_END_LOADS();
-        T2_MMA(4, 2, fb1);
-        T2_BARRIER();
-        // ---- phase 4: quadrant (a1, b0); retire tile kt+1 (3 half-tiles of tile kt+2 may stay in flight)
-        if (kt + 2 < nk) {
-            stage_w(cur, 1, kt + 2);
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        T2_BARRIER();
-        __builtin_amdgcn_sched_barrier(0);
-        T2_MMA(4, 0, fb0);
-        T2_BARRIER();
-    }
-    if (wave < 4) T2_BARRIER();   // matches the stagger barrier of waves 4-7
-    };
-    if (wave_active) pipeline(std::true_type()); else pipeline(std::false_type());
-
-    // ---- epilogue: lane holds C[m = m0 + wm*128 + 16 i + fr][n = n0 + wn*64 + 16 j + 4g .. +3]
-    TDC_STAMP(2);
-    if (p.debug == 1) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
-        return;
-    }
-    if (p.debug != 2) {
-        T2_EPI_BARRIER();   // every wave is past its last LDS read: the pipeline buffers become staging space
-        if (!wave_active) return;
-        if (epilogue_staged<T, false>(p, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn_ * 64, lane)) {
-#ifdef TDC_GEMM_DIAG
-            TDC_STAMP(3);
-            if (p.debug == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            TDC_STAMP(4);
-#endif
-            return;
-        }
-    }
-    epilogue<T, 8, 4>(p, acc, m0 + wm * 128, n0 + wn_ * 64, fr, g);
-}
-
-// ======================================================================================================================
-// Persistent form of the 256^2 kernel: one workgroup per CU walks its tiles (static round-robin inside the XCD's contiguous
-// chunk of the grouped tile order, so the 32 workgroups of an XCD still cover the same patch of tiles at any time).
-// In-kernel stamps of the one-tile-per-workgroup kernel (tools/gemm_stamps.cpp) showed ~3 us per tile - 7 % of a K=1152
-// tile - between the last store of one workgroup and the first MFMA of the next (dispatch + first loads from HBM), and
-// that the C-tile drain itself is store-issue bound (~73 cycles per 1-KiB store instruction and CU), not latency bound.
-// Here the staging stream simply runs on across the tile seam: the last two K iterations of a tile stage K tiles 0 and 1
-// of the NEXT tile (the staging cursor switches its base pointers between phase 1 and phase 2 of iteration nk-2), the
-// epilogue stages through 4 KiB per wave BESIDE the 128 KiB pipeline buffers, and the next main loop starts with its
-// operands already in LDS.  Staging addresses are an SGPR tile base + 32-bit per-lane offsets (a_map must be identity).
-constexpr int T2P_LDS = T2_LDS + 8 * 4096;    // 160 KiB
-
-template <class T, bool LNF, bool FP8>  // LNF: LayerNorm-fold consumer (ln_stats != NULL): 5 more lane-held epilogue operands
-__global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
-    typedef typename VecOf<T>::v8 v8;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nwg = p.tiles_m * p.tiles_n;
-    // ---- this workgroup's tiles: ids base + l + G8 * j of XCD x's chunk [base, base + len) (same chunks as xcd_remap)
-    const int G8 = gridDim.x >> 3;
-    const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
-    const int cq = nwg >> 3, cr = nwg & 7;
-    const int chunk_base = (xcd < cr) ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
-    const int chunk_len = cq + (xcd < cr ? 1 : 0);
-    const int n_my = l < chunk_len ? (chunk_len - l + G8 - 1) / G8 : 0;
-    if (n_my == 0) return;
-
-    // ---- staging cursor: SGPR bases + per-lane byte offsets of the tile being staged
-    const int srow = lane >> 3;
-    const int schunk = (lane & 7) ^ srow;
-    unsigned a_so[2][2], w_so[2][2];
-    const char* a_base;
-    const char* w_base;
-    auto set_stage_tile = [&](int m0, int n0) {
-        a_base = (const char*)p.A + (long long)m0 * p.lda * 2;
-        w_base = (const char*)p.W + (long long)n0 * p.ldw * 2;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int r = (wave * 2 + j) * 8 + srow;                       // row within the half (0..127)
-                int am = (r >> 6) * 128 + h * 64 + (r & 63);
-                int wn = (r >> 5) * 64 + h * 32 + (r & 31);
-                if (am > p.M - 1 - m0) am = p.M - 1 - m0;
-                if (wn > p.N - 1 - n0) wn = p.N - 1 - n0;
-                a_so[h][j] = (unsigned)(am * p.lda + schunk * 8) * 2u;
-                w_so[h][j] = (unsigned)(wn * p.ldw + schunk * 8) * 2u;
-            }
-    };
-    const int lds_stage = wave * 2 * 1024;
-    // one half-tile (2 x 1 KiB per wave) from the SGPR source `src` (tile base + K offset) + the per-lane offsets
-    auto stage_a = [&](int buf, int h, const char* src) {
-        char* dst = smem + buf * T2_BUF + h * T2_HALF + lds_stage;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(src + a_so[h][0]), LDS_PTR(dst), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(GLB_PTR(src + a_so[h][1]), LDS_PTR(dst + 1024), 16, 0, 0);
-    };
-    auto stage_w = [&](int buf, int h, const char* src) {
-        char* dst = smem + buf * T2_BUF + (2 + h) * T2_HALF + lds_stage;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(src + w_so[h][0]), LDS_PTR(dst), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(GLB_PTR(src + w_so[h][1]), LDS_PTR(dst + 1024), 16, 0, 0);
-    };
-
-    const int wm = (wave >> 1) & 1, wn_ = (wave & 1) | ((wave >> 2) << 1);
-    const int fr = lane & 15, g = lane >> 4;
-    int a_off[4], w_off[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = wm * 64 + i * 16 + fr;
-        a_off[i] = r * 128 + ((g ^ (r & 7)) << 4);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = wn_ * 32 + j * 16 + fr;
-        w_off[j] = r * 128 + ((g ^ (r & 7)) << 4);
-    }
-
-    f32x4 acc[8][4];
-    v8 fa[4][2], fb0[2][2], fb1[2][2];
-    const int nk = p.K / 64;        // >= 2 (host)
-    int par = 0;                    // LDS buffer of the current tile's K tile 0
-
-    // running staging sources (SGPR pairs): pa1 = A source of the A1 half staged in phase 1 (K tile kt+1), pa2 / pw2 =
-    // A / W source of K tile kt+2.  They advance by one K tile (128 B) per iteration behind the last MFMA cluster and are
-    // re-based at the tile seam, so no address arithmetic sits in a load segment (the LDS-read -> barrier -> MFMA path).
-    const char *pa1, *pa2, *pw2;
-    // main loop of ONE tile; MORE = another tile follows (its first two K tiles are staged by the last two iterations),
-    // (m1, n1) = that tile's origin
-    auto tile_loop = [&](auto active_c, auto more_c, int m1, int n1) {
-        constexpr bool active = decltype(active_c)::value;
-        constexpr bool MORE = decltype(more_c)::value;
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = (kt + par) & 1, nxt = cur ^ 1;
-            const bool s1 = kt + 1 < nk, s2 = kt + 2 < nk;
-            // ---- phase 1: quadrant (a0, b0)
-            T2_LOAD_B(fb0, cur, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            T2_LOAD_A(cur, 0);
-            __builtin_amdgcn_sched_barrier(0);      // LDS reads first: an LDS-DMA issue ahead of them delays the barrier
-            if (MORE || s1) stage_a(nxt, 1, pa1);
-            T2_END_LOADS();
-            T2_MMA(0, 0, fb0);
-            T2_BARRIER();
-            // the staging cursor crosses the tile seam here: everything staged from now on belongs to the next tile
-            if (MORE && kt == nk - 2) {
-                set_stage_tile(m1, n1);
-                pa2 = a_base; pw2 = w_base;
-            }
-            // ---- phase 2: quadrant (a0, b1)
-            T2_LOAD_B(fb1, cur, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (MORE || s2) stage_a(cur, 0, pa2);
-            T2_END_LOADS();
-            T2_MMA(0, 2, fb1);
-            T2_BARRIER();
-            // ---- phase 3: quadrant (a1, b1)
-            T2_LOAD_A(cur, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (MORE || s2) stage_w(cur, 0, pw2);
-            T2_END_LOADS();
-            T2_MMA(4, 2, fb1);
-            T2_BARRIER();
-            // ---- phase 4: quadrant (a1, b0); retire K tile kt+1 (3 half-tiles of kt+2 may stay in flight)
-            if (MORE || s2) {
-                stage_w(cur, 1, pw2);
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            T2_BARRIER();
-            __builtin_amdgcn_sched_barrier(0);
-            T2_MMA(4, 0, fb0);
-            pa1 = pa2; pa2 += 128; pw2 += 128;
-            __builtin_amdgcn_sched_barrier(0);
-            T2_BARRIER();
-        }
-    };
-
-    int id = chunk_base + l;
-    int tm, tn;
-    tile_coords(id, p.tiles_m, p.tiles_n, tm, tn);
-    int m0 = tm * 256, n0 = tn * 256;
-    // lane L keeps the epilogue operands of the tile being computed (EpiLane: column n0 + wn*64 + L, rows m0 + wm*128 +
-    // L and + 64 + L); the first set is waited for here, compiler-visibly, before any staging load is in flight
-    auto load_epi_lane = [&](int m0_, int n0_) {
-        EpiLane e = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int n = n0_ + wn_ * 64 + lane;
-        if (n > p.N - 1) n = p.N - 1;
-        if (p.bias) e.bias = p.bias[n];
-        if (LNF) {
-            e.c1 = p.ln_c1[n];
-            int r0 = m0_ + wm * 128 + lane, r1 = r0 + 64;
-            if (r0 > p.M - 1) r0 = p.M - 1;
-            if (r1 > p.M - 1) r1 = p.M - 1;
-            const float2 s0 = *(const float2*)(p.ln_stats + 2 * (long long)r0);
-            const float2 s1 = *(const float2*)(p.ln_stats + 2 * (long long)r1);
-            e.mean0 = s0.x; e.rstd0 = s0.y; e.mean1 = s1.x; e.rstd1 = s1.y;
-        }
-        return e;
-    };
-    // Between its load (one tile ahead, at the start of the previous epilogue) and its use the set is parked in the wave's
-    // epilogue staging region, which is idle during the main loop: no VGPR stays live across the K loop for it.
-    EpiLane* el_park = (EpiLane*)(smem + T2_LDS + wave * 4096) + lane;
-    *el_park = load_epi_lane(m0, n0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    // ---- prologue of the first tile: K tile 0 complete + K tile 1's A0 B0 B1
-    set_stage_tile(m0, n0);
-    stage_a(0, 0, a_base); stage_w(0, 0, w_base); stage_w(0, 1, w_base); stage_a(0, 1, a_base);
-    stage_a(1, 0, a_base + 128); stage_w(1, 0, w_base + 128); stage_w(1, 1, w_base + 128);
-    pa1 = a_base + 128; pa2 = a_base + 256; pw2 = w_base + 256;
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    T2_BARRIER();
-    if (wave >= 4) T2_BARRIER();      // stagger (see gemm256_kernel)
-
-    for (int it = 0; it < n_my; ++it) {
-        const bool more = it + 1 < n_my;
-        int m1 = 0, n1 = 0;
-        if (more) {
-            int tm1, tn1;
-            tile_coords(id + G8, p.tiles_m, p.tiles_n, tm1, tn1);
-            m1 = tm1 * 256; n1 = tn1 * 256;
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const bool wave_active = n0 + wn_ * 64 < p.N;
-#ifdef TDC_GEMM_DIAG
-        if (p.stamps && threadIdx.x == 0) {
-            p.stamps[(size_t)id * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-            p.stamps[(size_t)id * 8 + 6] = __builtin_amdgcn_s_getreg((3 << 11) | 20);
-            __builtin_amdgcn_sched_barrier(0);
-            p.stamps[(size_t)id * 8 + 0] = p.stamps[(size_t)id * 8 + 1] = __builtin_amdgcn_s_memrealtime();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#endif
-        if (more) {
-            if (wave_active) tile_loop(std::true_type(), std::true_type(), m1, n1);
-            else tile_loop(std::false_type(), std::true_type(), m1, n1);
-        } else {
-            if (wave_active) tile_loop(std::true_type(), std::false_type(), m1, n1);
-            else tile_loop(std::false_type(), std::false_type(), m1, n1);
-        }
-        par ^= nk & 1;
-#ifdef TDC_GEMM_DIAG
-        if (p.stamps && threadIdx.x == 0) {
-            __builtin_amdgcn_sched_barrier(0);
-            p.stamps[(size_t)id * 8 + 2] = __builtin_amdgcn_s_memrealtime();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#endif
-        // ---- epilogue (no barrier: every wave stages through its own 4 KiB beside the pipeline buffers).  The lane id is
-        // made opaque per tile so that the epilogue's lane-derived addresses are recomputed here instead of being hoisted
-        // out of the tile loop, kept live across the main loop and spilled (their scratch reloads would sit behind the
-        // next tile's staged loads in the in-order vmcnt queue).
-        int elane = lane;
-        asm volatile("" : "+v"(elane));
-        const EpiLane el = *el_park;
-        EpiLane el_next = el;
-        if (more) el_next = load_epi_lane(m1, n1);                       // complete by the vmcnt(0) below
-        if (wave_active && p.debug != 1) {
-            char* region = smem + T2_LDS + wave * 4096;
-            const int mb = m0 + wm * 128, nb = n0 + wn_ * 64;
-            if (LNF) {
-                epilogue_staged_f<T, true, true>(p, acc, region, mb, nb, elane, el);   // host: a staged variant exists
-            } else if (!epilogue_staged<T, true>(p, acc, region, mb, nb, elane, el)) {
-                epilogue<T, 8, 4, true>(p, acc, mb, nb, elane & 15, elane >> 4, el);
-            }
-        } else if (p.debug == 1) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
-        }
-#ifdef TDC_GEMM_DIAG
-        if (p.stamps && threadIdx.x == 0) {
-            __builtin_amdgcn_sched_barrier(0);
-            p.stamps[(size_t)id * 8 + 3] = p.stamps[(size_t)id * 8 + 4] = __builtin_amdgcn_s_memrealtime();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#endif
-        // A compiler-visible vmcnt(0): without it the waitcnt pass protects the fragment registers of the next main loop
-        // against this epilogue's (long finished) loads with a vmcnt(0) INSIDE the K loop, which would drain the staging
-        // pipeline every iteration.  Here it only waits for the acknowledgement of the last stores.  Unconditional: the
-        // pass cannot tell that !more leaves the loop.
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        *el_park = el_next;
-        id += G8; m0 = m1; n0 = n1;
-    }
-    if (wave < 4) T2_BARRIER();   // matches the stagger barrier of waves 4-7
-}
-#undef T2_END_LOADS
-#undef T2_BARRIER
-#undef T2_LOAD_A
-#undef T2_LOAD_B
-#undef T2_MMA
-
-// workgroups of the persistent kernel = CUs of the device rounded down to a multiple of 8 (one per CU: 160 KiB of LDS);
-// 0 disables it (TDC_GEMM_PERSIST=0, or a device whose LDS cannot hold 160 KiB per workgroup)
-inline int persistent_grid() {
-    static int grid = -1;
-    if (grid < 0) {
-        const char* e = getenv("TDC_GEMM_PERSIST");
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if ((e && atoi(e) == 0) || hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-            prop.sharedMemPerBlock < (size_t)T2P_LDS)
-            grid = 0;
-        else
-            grid = (prop.multiProcessorCount / 8) * 8;
-    }
-    return grid;
-}
-
-// kernel choice: the 256^2 8-phase kernel needs enough tiles to fill the 256 CUs; TDC_GEMM_FORCE=128|256 overrides
-inline bool use_256(int M, int N, int K) {
-    static int force = -1;
-    if (force < 0) {
-        const char* e = getenv("TDC_GEMM_FORCE");
-        force = e ? atoi(e) : 0;
-    }
-    if (force == 128) return false;
-    if (force == 256) return true;
-    const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256);
-    return t256 >= 192 && K >= 128;
-}
-
-#ifdef TDC_GEMM_DIAG
-}
-unsigned long long* tdc_gemm_diag_stamps = nullptr;   // set by tools/gemm_stamps.cpp
-namespace {
-#endif
-template <class T, bool FP8>
-int launch(const tdc_gemm_desc* d, hipStream_t st) {
-    GemmArgs a;
-    a.A = d->A; a.W = d->W; a.C = d->C; a.bias = d->bias; a.res = d->res;
-    a.lda = d->lda; a.ldw = d->ldw; a.ldc = d->ldc; a.ldres = d->ldres;
-    a.M = d->M; a.N = d->N; a.K = d->K;
-    if (FP8) { a.lda /= 2; a.ldw /= 2; a.K /= 2; }     // kernels address A / W in 2-byte units
-    a.out_f32 = d->out_f32; a.res_f32 = d->res_f32; a.act = d->act;
-    a.x16 = d->x16; a.ldx16 = d->ldx16; a.ln_part = d->ln_part; a.ln_stats = d->ln_stats; a.ln_c1 = d->ln_c1;
-    { const char* e = getenv("TDC_GEMM_DEBUG"); a.debug = e ? atoi(e) : 0; }
-#ifdef TDC_GEMM_DIAG
-    a.stamps = tdc_gemm_diag_stamps;
-#endif
-    a.am = {d->a_map.seg, d->a_map.stride, d->a_map.off, d->a_map.inner};
-    a.cm = {d->c_map.seg, d->c_map.stride, d->c_map.off, d->c_map.inner};
-    a.rm = {d->r_map.seg, d->r_map.stride, d->r_map.off, d->r_map.inner};
-    if (use_256(a.M, a.N, a.K)) {
-        a.tiles_m = (a.M + 255) / 256;
-        a.tiles_n = (a.N + 255) / 256;
-        static bool attr256 = false;
-        if (!attr256) {
-            HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm256_kernel<T, FP8>,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS));
-            attr256 = true;
-        }
-        // persistent form: more tiles than CUs, identity a_map, K >= 128, in-tile byte offsets fit 32 bits
-        // (the LayerNorm-fold instance only carries the LDS-staged epilogues)
-        const int G = persistent_grid();
-        const bool fold_ok = !d->ln_stats || (!(d->ldc & 7) && !((uintptr_t)d->C & 15) &&
-                                              d->N % (d->act == TDC_ACT_SWIGLU ? 16 : 8) == 0);
-        if (G > 0 && a.tiles_m * a.tiles_n > G && d->a_map.seg == 0 && a.K >= 128 && fold_ok &&
-            256ll * a.lda * 2 < (1ll << 31) && 256ll * a.ldw * 2 < (1ll << 31)) {
-            static bool attr256p = false;
-            if (!attr256p) {
-                HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm256p_kernel<T, false, FP8>,
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, T2P_LDS));
-                HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm256p_kernel<T, true, FP8>,
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, T2P_LDS));
-                attr256p = true;
-            }
-            if (d->ln_stats) hipLaunchKernelGGL((gemm256p_kernel<T, true, FP8>), dim3(G), dim3(512), T2P_LDS, st, a);
-            else hipLaunchKernelGGL((gemm256p_kernel<T, false, FP8>), dim3(G), dim3(512), T2P_LDS, st, a);
-            return (int)hipGetLastError();
-        }
-        hipLaunchKernelGGL((gemm256_kernel<T, FP8>), dim3(a.tiles_m * a.tiles_n), dim3(512), T2_LDS, st, a);
-        return (int)hipGetLastError();
-    }
-    a.tiles_m = (a.M + BM - 1) / BM;
-    a.tiles_n = (a.N + BN - 1) / BN;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_kernel<T, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          4 * TILE_BYTES));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm_kernel<T, FP8>), dim3(a.tiles_m * a.tiles_n), dim3(256), 4 * TILE_BYTES, st, a);
-    return (int)hipGetLastError();
-}
-
-}  // namespace
 
 extern "C" int tdc_gemm(const tdc_gemm_desc* d, void* stream) {
     if (!d || !d->A || !d->W || !d->C || d->M <= 0 || d->N <= 0 || d->K <= 0) return TDC_E_BADARG;
@@ -1212,11 +46,7 @@ extern "C" int tdc_gemm(const tdc_gemm_desc* d, void* stream) {
             return TDC_E_BADARG;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (d->in_fp8) {
-        if (d->dtype == TDC_F16) return launch<f16, true>(d, st);
-        if (d->dtype == TDC_BF16) return launch<bf16, true>(d, st);
-        return TDC_E_BADARG;
-    }
+    if (d->in_fp8) return tdc_gemm_fp8_impl(d, st);
     if (d->dtype == TDC_F16) return launch<f16, false>(d, st);
     if (d->dtype == TDC_BF16) return launch<bf16, false>(d, st);
     return TDC_E_BADARG;
