@@ -177,6 +177,8 @@ def main():
                     help="fp8 (BASELINE config 5): e4m3 operands for the towers' LayerNorm-fed GEMMs (qkv, fc1) through "
                          "v_mfma_f32_16x16x128_f8f6f4, bf16 everywhere else")
     ap.add_argument("--px", type=int, default=384, help="SigLIP input size (DINO uses px-6: 378); 336 -> 336/336")
+    ap.add_argument("--fp8-level", type=int, default=1, choices=[1, 2],
+                    help="--dtype fp8: 1 = qkv / fc1 (quantised by the LayerNorm kernel), 2 = also out-proj / fc2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tower-batch", type=int, default=512)
     ap.add_argument("--two-streams", type=int, default=0, help="run the two towers on two HIP streams")
@@ -215,7 +217,7 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(0)
     sd = random_state_dict(H, K, dev, gen, siglip_px=px_s)
     enc = VideoEncoder(sd, cfg, dtype=dtype, device=dev, siglip_heads=16, dino_heads=24, qformer_heads=12,
-                       tower_batch=args.tower_batch, fp8_towers=args.dtype == "fp8")
+                       tower_batch=args.tower_batch, fp8_towers=args.fp8_level if args.dtype == "fp8" else 0)
     enc.two_streams = bool(args.two_streams)
     wav = None
     if args.audio:
@@ -321,7 +323,7 @@ def main():
         "metric": "frames/sec encoded+compressed (576->K tokens) at T=%d" % T,
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "fp8 (e4m3 qkv/fc1 operands) + bf16" if args.dtype == "fp8" else args.dtype, "data": "synthetic",
+        "dtype": ("fp8 (e4m3 operands: %s) + bf16" % ("all four tower GEMMs" if args.fp8_level == 2 else "qkv / fc1")) if args.dtype == "fp8" else args.dtype, "data": "synthetic",
         "config": {"workload": "one %d-frame video, SigLIP-so400m/14@%d + DINOv2-giant/14@%d towers (729 patches -> 576 "
                                "tokens), SVA 576->144, mm_projector -> H=%d, Q-Former TDC K=%d (N=156, 12 prompt ids), "
                                "random-init weights, frame cap lifted to T, LLM stubbed%s"

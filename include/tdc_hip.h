@@ -65,6 +65,12 @@ typedef struct {
     int in_fp8;
 } tdc_gemm_desc;
 int tdc_gemm(const tdc_gemm_desc* d, void* stream);
+/* per-row e4m3 quantisation of a 16-bit matrix x [rows, ldx] (cols % 8 == 0, cols <= 4608): y8 [rows, ldy8] = x / s_a[r]
+ * with s_a[r] = max|x[r]| / 448 (zero bytes up to the next multiple of 128 columns when ldy8 allows), stats[r] =
+ * (0, s_a[r] * wscale) - the operands of an fp8-operand tdc_gemm whose input does not come out of a LayerNorm (the
+ * attention output, the MLP hidden). */
+int tdc_quantize_rows_fp8(const void* x, int ldx, int rows, int cols, int dtype, void* y8, int ldy8, float* stats,
+                          float wscale, void* stream);
 /* (mean, M2) partials [slots, rows, 2] of `slots` 64-column slots per row -> stats [rows, 2] = (mean, 1 / sqrt(var + eps)), biased
  * variance over slots * 64 columns (nn.LayerNorm); Chan's parallel combination in a fixed order. */
 int tdc_ln_finalize(const float* ln_part, int slots, int rows, float eps, float* stats, void* stream);
@@ -183,6 +189,7 @@ typedef struct {
     /* fp8 towers (tdc_vit_model.fp8): qkv.w / fc1.w hold e4m3 bytes [n, round_up(k, 128)] with these per-tensor scales;
      * zeros [>= max n] fp32 zeros (the ln_c1 operand of an fp8-operand tdc_gemm) */
     float qkv_wscale, fc1_wscale; const float* zeros;
+    float out_wscale, fc2_wscale;    /* fp8 level 2: out.w / fc2.w are e4m3 too */
 } tdc_vit_layer;
 typedef struct {
     int dtype, dim, heads, head_dim, n_layers, patch, has_cls;
@@ -194,8 +201,9 @@ typedef struct {
     const float *lnf_g, *lnf_b;      /* final LayerNorm (NULL: take the raw residual stream, SigLIP hidden_states[-1]) */
     const tdc_vit_layer* layers_host;
     int fused;                       /* pre-LayerNorms folded into the qkv / fc1 GEMMs (dim % 64 == 0) */
-    int fp8;                         /* the LayerNorms emit e4m3 rows + per-row scales and the qkv / fc1 GEMMs run on fp8
-                                        operands (dim % 128 == 0; excludes `fused`); everything else stays 16-bit */
+    int fp8;                         /* 1: the LayerNorms emit e4m3 rows + per-row scales and the qkv / fc1 GEMMs run on fp8
+                                        operands (dim % 128 == 0; excludes `fused`); 2: out-proj / fc2 as well, their inputs
+                                        (attention output, MLP hidden) quantised per row by tdc_quantize_rows_fp8 */
 } tdc_vit_model;
 size_t tdc_vit_workspace_bytes(const tdc_vit_model* m, int B, int H, int W);
 /* px [B,3,H,W] (fp32 when px_f32 else 16-bit) -> out [B*out_grid*out_grid, ldo] 16-bit; idx0/idx1/frac: bilinear tables

@@ -15,19 +15,30 @@ struct VitWs {
     size_t patches, x32, h16, qkv, attn, mlp, part, stats, total;   // fp8 towers: h16 holds the e4m3 LayerNorm rows
 };
 
+// row stride of the 16-bit MLP hidden buffer: fc1's output width (SwiGLU halves it), at least fc2's (padded) K
+int vit_mlp_ld(const tdc_vit_model* m) {
+    if (!m->n_layers) return 0;
+    const tdc_vit_layer& L = m->layers_host[0];
+    const int n1 = m->act == TDC_ACT_SWIGLU ? L.fc1.n / 2 : L.fc1.n;
+    return n1 > L.fc2.k ? n1 : L.fc2.k;
+}
+
 VitWs vit_layout(const tdc_vit_model* m, int B, int H, int W) {
     const int gh = H / m->patch, gw = W / m->patch;
     const size_t P = (size_t)gh * gw, S = P + m->has_cls, rows = (size_t)B * S;
     const int Dp = pad64i(m->dim);
     const int kp = m->patch_lin.k;
     const int qkv_w = m->n_layers ? m->layers_host[0].qkv.n : 0;
-    const int mlp_w = m->n_layers ? m->layers_host[0].fc2.k : 0;
+    const int mlp_w = vit_mlp_ld(m);
     VitWs w;
     size_t off = 0;
     w.patches = off; off += al256((size_t)B * P * kp * 2);
     w.x32 = off;     off += al256(rows * Dp * 4);
     w.h16 = off;     off += al256(rows * Dp * 2);
-    w.qkv = off;     off += al256(rows * qkv_w * 2);
+    {   // fp8 level 2 parks the e4m3 MLP hidden (rows x fc2.k bytes) in the qkv buffer
+        size_t qb = rows * qkv_w * 2, mb = (m->fp8 >= 2 && m->n_layers) ? rows * (size_t)m->layers_host[0].fc2.k : 0;
+        w.qkv = off; off += al256(qb > mb ? qb : mb);
+    }
     w.attn = off;    off += al256(rows * Dp * 2);
     w.mlp = off;     off += al256(rows * mlp_w * 2);
     w.part = off;    off += m->fused ? al256(rows * (size_t)(Dp / 64) * 8) : 0;
@@ -57,6 +68,17 @@ int layernorm_fp8(const float* x, int ldx, void* y8, int ldy8, float* stats, flo
     d.rows = rows; d.cols = cols; d.dtype = dtype;
     d.y8 = y8; d.ldy8 = ldy8; d.y8_stats = stats; d.y8_wscale = wscale;
     return tdc_layernorm(&d, st);
+}
+
+// fp32 residual-stream update x32 += s_a s_w (A8 W8^T) + b on fp8 operands
+int gemm_fp8_rmw(const void* A8, int lda, const tdc_lin& L, float* x32, int ld, int M, int dtype, const float* stats,
+                 const float* zeros, void* st) {
+    tdc_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.A = A8; d.lda = lda; d.W = L.w; d.ldw = L.k; d.C = x32; d.ldc = ld; d.bias = L.b; d.res = x32; d.ldres = ld;
+    d.M = M; d.N = L.n; d.K = L.k; d.dtype = dtype; d.out_f32 = 1; d.res_f32 = 1; d.in_fp8 = 1;
+    d.ln_stats = stats; d.ln_c1 = zeros;
+    return tdc_gemm(&d, st);
 }
 
 int gemm_fp8(const void* A8, int lda, const tdc_lin& L, void* C, int ldc, int M, int dtype, int act, const float* stats,
@@ -270,6 +292,7 @@ extern "C" int tdc_vit_fwd(const tdc_vit_model* m, const void* px, int px_f32, i
     float* part = (float*)(ws + w.part);
     float* stats = (float*)(ws + w.stats);
     const int slots = D / 64;
+    const int mlp_ld = vit_mlp_ld(m);            // row stride of the MLP hidden buffer (16-bit values)
     for (int l = 0; l < m->n_layers; ++l) {
         const tdc_vit_layer& L = m->layers_host[l];
         if (m->fp8) {
@@ -304,10 +327,21 @@ extern "C" int tdc_vit_fwd(const tdc_vit_model* m, const void* px, int px_f32, i
                 RET_IF(gemm(mlp, L.fc2.k, L.fc2, x32, Dp, rows, dt, TDC_ACT_NONE, 1, x32, Dp, 1, ident, ident, stream));
             }
         } else if (m->fp8) {
-            RET_IF(gemm(attn, Dp, L.out, x32, Dp, rows, dt, TDC_ACT_NONE, 1, x32, Dp, 1, ident, ident, stream));
+            if (m->fp8 >= 2) {   // attention output -> e4m3 rows (in h16: the LayerNorm rows are consumed) -> out-proj on fp8
+                RET_IF(tdc_quantize_rows_fp8(attn, Dp, rows, Dp, dt, h16, L.out.k, stats, L.out_wscale, stream));
+                RET_IF(gemm_fp8_rmw(h16, L.out.k, L.out, x32, Dp, rows, dt, stats, L.zeros, stream));
+            } else {
+                RET_IF(gemm(attn, Dp, L.out, x32, Dp, rows, dt, TDC_ACT_NONE, 1, x32, Dp, 1, ident, ident, stream));
+            }
             RET_IF(layernorm_fp8(x32, Dp, h16, L.fc1.k, stats, L.fc1_wscale, L.ln2_g, L.ln2_b, m->eps, rows, D, dt, stream));
-            RET_IF(gemm_fp8(h16, L.fc1.k, L.fc1, mlp, L.fc2.k, rows, dt, m->act, stats, L.zeros, stream));
-            RET_IF(gemm(mlp, L.fc2.k, L.fc2, x32, Dp, rows, dt, TDC_ACT_NONE, 1, x32, Dp, 1, ident, ident, stream));
+            RET_IF(gemm_fp8(h16, L.fc1.k, L.fc1, mlp, mlp_ld, rows, dt, m->act, stats, L.zeros, stream));
+            if (m->fp8 >= 2) {   // MLP hidden -> e4m3 rows (in the qkv buffer, free after the attention) -> fc2 on fp8
+                const int mlp_n = m->act == TDC_ACT_SWIGLU ? L.fc1.n / 2 : L.fc1.n;   // columns fc1 writes (pad columns: 0)
+                RET_IF(tdc_quantize_rows_fp8(mlp, mlp_ld, rows, mlp_n, dt, qkv, L.fc2.k, stats, L.fc2_wscale, stream));
+                RET_IF(gemm_fp8_rmw(qkv, L.fc2.k, L.fc2, x32, Dp, rows, dt, stats, L.zeros, stream));
+            } else {
+                RET_IF(gemm(mlp, L.fc2.k, L.fc2, x32, Dp, rows, dt, TDC_ACT_NONE, 1, x32, Dp, 1, ident, ident, stream));
+            }
         } else {
             RET_IF(gemm(attn, Dp, L.out, x32, Dp, rows, dt, TDC_ACT_NONE, 1, x32, Dp, 1, ident, ident, stream));
             RET_IF(layernorm(x32, Dp, h16, Dp, L.ln2_g, L.ln2_b, m->eps, rows, D, dt, stream));

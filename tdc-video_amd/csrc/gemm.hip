@@ -40,8 +40,11 @@ extern "C" int tdc_gemm(const tdc_gemm_desc* d, void* stream) {
             ((uintptr_t)d->ln_part & 7))
             return TDC_E_BADARG;
     }
-    if (d->ln_stats) {   /* consumer: 16-bit output without residual, row statistics indexed by the A / C row */
-        if (!d->ln_c1 || d->out_f32 || d->res || d->a_map.seg != 0 || ((uintptr_t)d->ln_stats & 7) ||
+    if (d->ln_stats) {   /* consumer: 16-bit output without residual - or, with fp8 operands, the fp32 residual-stream
+                            update (identity row maps); row statistics indexed by the A / C row */
+        const bool rmw = d->in_fp8 && d->out_f32 && d->res && d->res_f32 && d->act == TDC_ACT_NONE && !d->x16 &&
+                         d->c_map.seg == 0 && d->r_map.seg == 0;
+        if (!d->ln_c1 || (!rmw && (d->out_f32 || d->res)) || d->a_map.seg != 0 || ((uintptr_t)d->ln_stats & 7) ||
             ((uintptr_t)d->ln_c1 & 15))
             return TDC_E_BADARG;
     }

@@ -275,7 +275,8 @@ __device__ __forceinline__ void epilogue_f(const GemmArgs& p, f32x4 (&acc)[MI][N
     else if (p.act == TDC_ACT_GELU_TANH) epi_tile<T, MI, NJ, TDC_ACT_GELU_TANH, 0, false, LB, FOLD>(p, acc, mbase, nbase, fr, g, el);
     else if (p.act == TDC_ACT_SWIGLU) epi_tile<T, MI, NJ, TDC_ACT_SWIGLU, 0, false, LB, FOLD>(p, acc, mbase, nbase, fr, g, el);
     else if (!p.out_f32 && res == 0) epi_tile<T, MI, NJ, 0, 0, false, LB, FOLD>(p, acc, mbase, nbase, fr, g, el);
-    else if (FOLD) return;                          // (host-checked: the fold only exists for 16-bit outputs without residual)
+    else if (p.out_f32 && res == 1 && FOLD) epi_tile<T, MI, NJ, 0, 1, true, LB, true>(p, acc, mbase, nbase, fr, g, el);
+    else if (FOLD) return;          // (host-checked: the fold exists for 16-bit outputs and for the fp32 residual update)
     else if (p.out_f32) {
         if (res == 1) epi_tile<T, MI, NJ, 0, 1, true, LB, false>(p, acc, mbase, nbase, fr, g, el);
         else if (res == 2) epi_tile<T, MI, NJ, 0, 2, true, LB, false>(p, acc, mbase, nbase, fr, g, el);
@@ -510,13 +511,14 @@ __device__ __forceinline__ void epi_staged_swiglu(const GemmArgs& p, f32x4 (&acc
 
 // fp32 output (+ fp32 residual).  EMIT (LayerNorm fusion, producer side): the updated row also goes out as 16-bit
 // (x16) together with the per-slot (mean, M2) partials - identity row maps, N % 64 == 0.
-template <class T, int RES, int ROWS, bool LB, bool EMIT>
+template <class T, int RES, int ROWS, bool LB, bool EMIT, bool FOLD = false>
 __device__ __forceinline__ void epi_staged32(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase, int nbase,
                                              int lane, const EpiLane& el) {
-    // ROWS = rows staged per pass (256-byte fp32 rows): 64 (16 KiB region) or 16 (4 KiB)
+    // ROWS = rows staged per pass (256-byte fp32 rows): 64 (16 KiB region) or 16 (4 KiB).  FOLD: the row / column
+    // operands of EpiOps (fp8 operands: the dequantisation scales of a residual-stream GEMM)
     typedef typename VecOf<T>::v4 v4;
     const int fr = lane & 15, g = lane >> 4;
-    EpiOps<8, 4, LB, false> ops;
+    EpiOps<8, 4, LB, FOLD> ops;
     ops.load(p, mbase, nbase, fr, g, el);
     constexpr int NPASS = 128 / ROWS, QP = ROWS / 4;      // QP read-back instructions (4 rows x 256 B each) per pass
     // The residual loads run as a ring of RING loads ahead of the read-back, independent of the staging passes (they
@@ -579,7 +581,11 @@ template <class T, bool SMALL, bool FOLD>
 __device__ __forceinline__ bool epilogue_staged_f(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase,
                                                   int nbase, int lane, const EpiLane& el) {
     const int res = p.res ? (p.res_f32 ? 1 : 2) : 0;
-    constexpr int R16 = SMALL ? 32 : 128, RSW = SMALL ? 64 : 128;
+    constexpr int R16 = SMALL ? 32 : 128, RSW = SMALL ? 64 : 128, R32 = SMALL ? 16 : 64;
+    if (FOLD && p.out_f32 && res == 1 && p.act == TDC_ACT_NONE) {      // fp8 operands of a residual-stream GEMM
+        epi_staged32<T, 1, R32, SMALL, false, true>(p, acc, region, mbase, nbase, lane, el);
+        return true;
+    }
     if (p.out_f32 || res == 1 || (p.ldc & 7) || ((uintptr_t)p.C & 15)) return false;
     if (p.act == TDC_ACT_SWIGLU) {
         if (p.N & 15) return false;
@@ -598,6 +604,7 @@ template <class T, bool SMALL>
 __device__ __forceinline__ bool epilogue_staged(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase,
                                                 int nbase, int lane, const EpiLane& el = EpiLane()) {
     constexpr int R32 = SMALL ? 16 : 64;
+    if (!SMALL && p.ln_stats && p.out_f32) return epilogue_staged_f<T, SMALL, true>(p, acc, region, mbase, nbase, lane, el);
     if (p.out_f32) {
         const int res = p.res ? (p.res_f32 ? 1 : 2) : 0;
         if (p.act != TDC_ACT_NONE || res == 2) return false;
@@ -853,12 +860,17 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
     if (n_my == 0) return;
 
     // ---- staging cursor: SGPR bases + per-lane byte offsets of the tile being staged
-    const int srow = lane >> 3;
-    const int schunk = (lane & 7) ^ srow;
     unsigned a_so[2][2], w_so[2][2];
     const char* a_base;
     const char* w_base;
     auto set_stage_tile = [&](int m0, int n0) {
+        // the lane-derived terms are recomputed from an opaque copy of the lane id on every call (once per tile): kept in
+        // registers across the K loop they would be spilled, and a scratch reload at the tile seam waits for every
+        // staged load in flight (in-order vmcnt)
+        int sl = lane;
+        asm volatile("" : "+v"(sl));
+        const int srow = sl >> 3;
+        const int schunk = (sl & 7) ^ srow;
         a_base = (const char*)p.A + (long long)m0 * p.lda * 2;
         w_base = (const char*)p.W + (long long)n0 * p.ldw * 2;
 #pragma unroll
@@ -1144,8 +1156,9 @@ int launch(const tdc_gemm_desc* d, hipStream_t st) {
         // persistent form: more tiles than CUs, identity a_map, K >= 128, in-tile byte offsets fit 32 bits
         // (the LayerNorm-fold instance only carries the LDS-staged epilogues)
         const int G = persistent_grid();
-        const bool fold_ok = !d->ln_stats || (!(d->ldc & 7) && !((uintptr_t)d->C & 15) &&
-                                              d->N % (d->act == TDC_ACT_SWIGLU ? 16 : 8) == 0);
+        const bool fold_ok = !d->ln_stats || (d->out_f32 && d->res && d->res_f32 && d->act == TDC_ACT_NONE) ||
+                             (!d->out_f32 && !(d->ldc & 7) && !((uintptr_t)d->C & 15) &&
+                              d->N % (d->act == TDC_ACT_SWIGLU ? 16 : 8) == 0);
         if (G > 0 && a.tiles_m * a.tiles_n > G && d->a_map.seg == 0 && a.K >= 128 && fold_ok &&
             256ll * a.lda * 2 < (1ll << 31) && 256ll * a.ldw * 2 < (1ll << 31)) {
             static bool attr256p = false;

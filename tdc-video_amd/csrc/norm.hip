@@ -308,3 +308,69 @@ extern "C" int tdc_ln_finalize(const float* ln_part, int slots, int rows, float 
                        rows, eps, stats);
     return (int)hipGetLastError();
 }
+
+// ---- per-row e4m3 quantisation of a 16-bit matrix (fp8 operands for GEMMs whose input is not produced by a LayerNorm:
+// the attention output and the MLP hidden).  One wave per row, the row in registers (8 values per lane and step):
+// y8 = x / s_a with s_a = max|x| / 448, stats = (0, s_a * wscale) exactly as tdc_layernorm's y8 output.
+namespace {
+template <class T, int NV8>
+__global__ __launch_bounds__(256) void quant_rows_kernel(const T* __restrict__ x, int ldx, int rows, int cols,
+                                                         unsigned char* __restrict__ y8, int ldy8, int pad_cols,
+                                                         float* __restrict__ stats, float wscale) {
+    typedef typename VecOf<T>::v8 v8;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[NV8][8];
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV8; ++i) {
+        const int c = (lane + i * 64) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+        if (c < cols) {
+            const v8 h = *(const v8*)(x + (long long)row * ldx + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[i][e] = (float)h[e]; amax = fmaxf(amax, fabsf(v[i][e])); }
+        }
+    }
+    amax = wave_max(amax);
+    const float sa = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / sa;
+#pragma unroll
+    for (int i = 0; i < NV8; ++i) {
+        const int c = (lane + i * 64) * 8;
+        if (c < pad_cols) {
+            int w0 = 0, w1 = 0;
+            if (c < cols) {
+                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][0] * inv, v[i][1] * inv, w0, false);
+                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][2] * inv, v[i][3] * inv, w0, true);
+                w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][4] * inv, v[i][5] * inv, w1, false);
+                w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][6] * inv, v[i][7] * inv, w1, true);
+            }
+            *(int2*)(y8 + (long long)row * ldy8 + c) = make_int2(w0, w1);
+        }
+    }
+    if (lane == 0) *(float2*)(stats + 2 * (long long)row) = make_float2(0.f, sa * wscale);
+}
+}  // namespace
+
+extern "C" int tdc_quantize_rows_fp8(const void* x, int ldx, int rows, int cols, int dtype, void* y8, int ldy8,
+                                     float* stats, float wscale, void* stream) {
+    if (!x || !y8 || !stats || rows <= 0 || cols <= 0 || (cols & 7) || (ldx & 7) || (ldy8 & 7) || ldy8 < cols ||
+        ((uintptr_t)x & 15) || ((uintptr_t)y8 & 7) || ((uintptr_t)stats & 7))
+        return TDC_E_BADARG;
+    int pad = (cols + 127) / 128 * 128;            // zero bytes up to the K tile of the consuming GEMM
+    if (pad > ldy8) pad = cols;
+    const int nv = (pad + 511) / 512;
+    dim3 grid((rows + 3) / 4), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char* y = (unsigned char*)y8;
+#define QLAUNCH(TT, NV) hipLaunchKernelGGL((quant_rows_kernel<TT, NV>), grid, block, 0, st, (const TT*)x, ldx, rows, cols, y, ldy8, pad, stats, wscale)
+#define QDISPATCH(TT)                                        \
+    if (nv <= 3) QLAUNCH(TT, 3); else if (nv <= 6) QLAUNCH(TT, 6); else if (nv <= 9) QLAUNCH(TT, 9); else return TDC_E_BADARG;
+    if (dtype == TDC_F16) { QDISPATCH(f16) } else if (dtype == TDC_BF16) { QDISPATCH(bf16) } else return TDC_E_BADARG;
+#undef QDISPATCH
+#undef QLAUNCH
+    return (int)hipGetLastError();
+}

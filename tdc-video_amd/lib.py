@@ -71,7 +71,8 @@ class VitLayer(C.Structure):
     _fields_ = [("ln1_g", C.c_void_p), ("ln1_b", C.c_void_p), ("ln2_g", C.c_void_p), ("ln2_b", C.c_void_p),
                 ("qkv", Lin), ("out", Lin), ("fc1", Lin), ("fc2", Lin),
                 ("qkv_c1", C.c_void_p), ("fc1_c1", C.c_void_p),
-                ("qkv_wscale", C.c_float), ("fc1_wscale", C.c_float), ("zeros", C.c_void_p)]
+                ("qkv_wscale", C.c_float), ("fc1_wscale", C.c_float), ("zeros", C.c_void_p),
+                ("out_wscale", C.c_float), ("fc2_wscale", C.c_float)]
 
 
 class VitModel(C.Structure):
@@ -119,6 +120,8 @@ class QformerModel(C.Structure):
 SIGNATURES = {
     "tdc_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
     "tdc_ln_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "tdc_quantize_rows_fp8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                        C.c_float, C.c_void_p]),
     "tdc_layernorm": (C.c_int, [C.POINTER(LnDesc), C.c_void_p]),
     "tdc_attention": (C.c_int, [C.POINTER(AttnDesc), C.c_void_p]),
     "tdc_im2col": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

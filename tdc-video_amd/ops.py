@@ -92,7 +92,8 @@ def gemm(a, w, bias=None, act=L.ACT_NONE, res=None, out=None, out_f32=False, M=N
     fp8 = a.dtype in FP8_DTYPES
     if fp8:
         assert w.dtype in FP8_DTYPES and K % 128 == 0 and out_dtype in (torch.float16, torch.bfloat16)
-        assert ln_stats is not None and res is None and not out_f32, "fp8 operands carry their scales in ln_stats"
+        assert ln_stats is not None, "fp8 operands carry their scales in ln_stats"
+        assert (res is None and not out_f32) or (out_f32 and res is not None and res.dtype == torch.float32)
     else:
         out_dtype = a.dtype
     assert (fp8 or a.dtype == w.dtype) and K % 64 == 0 and a.shape[1] >= K, (a.shape, w.shape)
@@ -131,7 +132,7 @@ def gemm(a, w, bias=None, act=L.ACT_NONE, res=None, out=None, out_f32=False, M=N
         assert ln_part.dtype == torch.float32 and ln_part.is_contiguous() and ln_part.numel() >= M * (N // 64) * 2
         d.x16, d.ldx16, d.ln_part = x16.data_ptr(), x16.stride(0), ln_part.data_ptr()
     if ln_stats is not None:
-        assert ln_c1 is not None and not out_f32 and res is None and a_map is None
+        assert ln_c1 is not None and a_map is None and (fp8 or (not out_f32 and res is None))
         assert ln_stats.dtype == torch.float32 and ln_stats.is_contiguous() and ln_stats.numel() >= 2 * M
         assert ln_c1.dtype == torch.float32 and ln_c1.is_contiguous() and ln_c1.numel() >= N
         d.ln_stats, d.ln_c1 = ln_stats.data_ptr(), ln_c1.data_ptr()
@@ -153,6 +154,24 @@ def ln_finalize(ln_part, slots, rows, eps, stats=None):
     assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.numel() >= 2 * rows
     L.check(L.load().tdc_ln_finalize(_ptr(ln_part), slots, rows, eps, _ptr(stats), _stream()), "tdc_ln_finalize")
     return stats
+
+
+def quantize_rows_fp8(x, cols, wscale, y8=None, stats=None):
+    """x [rows, ld] 16-bit -> (y8 [rows, round_up(cols, 128)] e4m3 bytes with per-row scales, stats [rows, 2] = (0, s_a *
+    wscale)): the A operand + ln_stats of an fp8-operand gemm whose input is not produced by a LayerNorm."""
+    _chk2d(x, "x")
+    rows = x.shape[0]
+    assert x.shape[1] >= cols and cols % 8 == 0
+    if y8 is None:
+        y8 = torch.empty(rows, (cols + 127) // 128 * 128, device=x.device, dtype=torch.uint8)
+    if stats is None:
+        stats = torch.empty(rows, 2, device=x.device, dtype=torch.float32)
+    _chk2d(y8, "y8")
+    assert y8.dtype in FP8_DTYPES and y8.shape[0] >= rows and y8.shape[1] >= cols
+    assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.numel() >= 2 * rows
+    L.check(L.load().tdc_quantize_rows_fp8(_ptr(x), x.stride(0), rows, cols, _dt(x), _ptr(y8), y8.stride(0),
+                                           _ptr(stats), float(wscale), _stream()), "tdc_quantize_rows_fp8")
+    return y8, stats
 
 
 def layernorm(x, gamma, beta, eps, cols, dtype, y16=None, y32=None, add=None, add_period=0, add_mode=0,

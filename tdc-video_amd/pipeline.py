@@ -81,7 +81,8 @@ class VideoEncoder:
                                    Lr.qkv_c1.data_ptr() if Lr.qkv_c1 is not None else None,
                                    Lr.fc1_c1.data_ptr() if Lr.fc1_c1 is not None else None,
                                    Lr.qkv.wscale or 0.0, Lr.fc1.wscale or 0.0,
-                                   Lr.fc1.zeros.data_ptr() if Lr.fc1.zeros is not None else None)
+                                   Lr.fc1.zeros.data_ptr() if Lr.fc1.zeros is not None else None,
+                                   Lr.out.wscale or 0.0, Lr.fc2.wscale or 0.0)
         m = L.VitModel()
         m.dtype = ops._dtcode(self.dtype)
         m.dim, m.heads, m.head_dim, m.n_layers, m.patch, m.has_cls = t.dim, t.heads, t.head_dim, len(t.layers), t.patch, \
@@ -95,7 +96,7 @@ class VideoEncoder:
         m.lnf_g, m.lnf_b = (fl[0].data_ptr(), fl[1].data_ptr()) if fl else (None, None)
         m.layers_host = layers
         m.fused = int(bool(t.fused))
-        m.fp8 = int(bool(t.get("fp8")))
+        m.fp8 = int(t.get("fp8") or 0)
         cache[(gh, gw)] = (m, layers, pos, cls_row)
         return cache[(gh, gw)]
 
@@ -153,10 +154,16 @@ class VideoEncoder:
         part = torch.empty(slots, B * S, 2, device=dev, dtype=torch.float32) if fused else None
         stats = torch.empty(B * S, 2, device=dev, dtype=torch.float32) if fused else None
         emit = dict(x16=h16, ln_part=part) if fused else {}
-        fp8 = bool(t.get("fp8"))
+        fp8 = int(t.get("fp8") or 0)
         if fp8:     # e4m3 LayerNorm rows (per-row scales in `stats`) for the fp8-operand qkv / fc1 GEMMs
             h8 = torch.empty(B * S, t.layers[0].qkv.w.shape[1], device=dev, dtype=torch.uint8)
             stats = torch.empty(B * S, 2, device=dev, dtype=torch.float32)
+        if fp8 >= 2:    # ... and e4m3 copies of the attention output / MLP hidden for out-proj / fc2
+            a8 = torch.empty(B * S, t.layers[0].out.w.shape[1], device=dev, dtype=torch.uint8)
+            m8 = torch.empty(B * S, t.layers[0].fc2.w.shape[1], device=dev, dtype=torch.uint8)
+            mlp_n = t.layers[0].fc1.w.shape[0] // (2 if t.act == "swiglu" else 1)
+            mlp_w = max(mlp_w, m8.shape[1])
+            mlp = torch.empty(B * S, mlp_w, device=dev, dtype=dt)
         for li, Lr in enumerate(t.layers):
             if fp8:
                 ops.layernorm(x32, Lr.ln1_g, Lr.ln1_b, t.eps, D, dt, y8=h8, y8_stats=stats, y8_wscale=Lr.qkv.wscale)
@@ -169,7 +176,12 @@ class VideoEncoder:
             ld = qkv.stride(0)
             ops.attention(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], attn, B, t.heads, t.head_dim, S, S, scale,
                           S * ld, S * ld, S * ld, S * attn.stride(0))
-            ops.gemm(attn, Lr.out.w, Lr.out.b, res=x32, out=x32, out_f32=True, **emit)
+            if fp8 >= 2:
+                ops.quantize_rows_fp8(attn, Dp, Lr.out.wscale, y8=a8, stats=stats)
+                ops.gemm(a8, Lr.out.w, Lr.out.b, res=x32, out=x32, out_f32=True, ln_stats=stats, ln_c1=Lr.out.zeros,
+                         out_dtype=dt)
+            else:
+                ops.gemm(attn, Lr.out.w, Lr.out.b, res=x32, out=x32, out_f32=True, **emit)
             if fused:
                 ops.ln_finalize(part, slots, B * S, t.eps, stats)
                 ops.gemm(h16, Lr.fc1.w, Lr.fc1.b, act=act, out=mlp, ln_stats=stats, ln_c1=Lr.fc1_c1)
@@ -179,7 +191,11 @@ class VideoEncoder:
             else:
                 ops.layernorm(x32, Lr.ln2_g, Lr.ln2_b, t.eps, D, dt, y16=h16)
                 ops.gemm(h16, Lr.fc1.w, Lr.fc1.b, act=act, out=mlp)
-            if fused and li + 1 < len(t.layers):
+            if fp8 >= 2:
+                ops.quantize_rows_fp8(mlp, mlp_n, Lr.fc2.wscale, y8=m8, stats=stats)
+                ops.gemm(m8, Lr.fc2.w, Lr.fc2.b, res=x32, out=x32, out_f32=True, ln_stats=stats, ln_c1=Lr.fc2.zeros,
+                         out_dtype=dt)
+            elif fused and li + 1 < len(t.layers):
                 ops.gemm(mlp, Lr.fc2.w, Lr.fc2.b, res=x32, out=x32, out_f32=True, **emit)
                 ops.ln_finalize(part, slots, B * S, t.eps, stats)
             else:

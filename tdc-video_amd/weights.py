@@ -90,8 +90,11 @@ def to_fp8(lin, dev):
 
 
 def fp8_enabled(dim, requested):
-    """fp8 (e4m3) operands for the GEMMs fed by a LayerNorm (qkv, fc1): widths that are whole 128-byte K tiles."""
-    return bool(requested) and dim % 128 == 0
+    """fp8 (e4m3) operand level of a tower of width `dim` (whole 128-byte K tiles only): 0 = none, 1 = the GEMMs fed by a
+    LayerNorm (qkv, fc1: the LayerNorm kernel quantises), 2 = also out-proj / fc2 (their inputs - attention output, MLP
+    hidden - go through tdc_quantize_rows_fp8).  `requested`: False / True (= 1) / 1 / 2."""
+    level = int(requested) if requested else 0
+    return level if dim % 128 == 0 else 0
 
 
 def fold_c1(lin):
@@ -188,6 +191,8 @@ def prep_siglip(sd, heads, dtype, dev, patch=14, eps=1e-6, fp8=False):
         Lr.fc2 = make_lin(sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"], dtype, dev)
         if t.fp8:
             Lr.qkv, Lr.fc1 = to_fp8(Lr.qkv, dev), to_fp8(Lr.fc1, dev)
+        if t.fp8 >= 2:
+            Lr.out, Lr.fc2 = to_fp8(Lr.out, dev), to_fp8(Lr.fc2, dev)
         t.layers.append(Lr)
         i += 1
     t.mlp = t.layers[0].fc1.n if t.layers else 0
@@ -239,6 +244,8 @@ def prep_dino(sd, heads, dtype, dev, patch=14, eps=1e-6, fp8=False):
         Lr.fc1_c1 = fold_c1(Lr.fc1) if f2 else None
         if t.fp8:
             Lr.qkv, Lr.fc1 = to_fp8(Lr.qkv, dev), to_fp8(Lr.fc1, dev)
+        if t.fp8 >= 2:
+            Lr.out, Lr.fc2 = to_fp8(Lr.out, dev), to_fp8(Lr.fc2, dev)
         t.layers.append(Lr)
         i += 1
     t.final_ln = (vec32(sd["layernorm.weight"], dev), vec32(sd["layernorm.bias"], dev))

@@ -274,11 +274,14 @@ def test_fullsize_ln_fusion_matches_layernorm_kernel(full_sd, dtype, tol, monkey
         assert ((a - b).abs().max() / a.abs().max()).item() < tol
 
 
-def test_fullsize_fp8_towers_close_to_bf16():
-    """BASELINE config 5's fp8 MFMA path at full depth / width (e4m3 operands for the towers' qkv / fc1 GEMMs): against the
-    bf16 path on the same random-init weights the emitted tokens differ by ~1 % RMS (measured 1.2e-2; the towers
-    themselves by 6 % / 19 % RMS - e4m3 has 3 mantissa bits and random-init weights offer nothing to average the
-    noise against) and the segment selection - the integer part of the path - is unchanged."""
+@pytest.mark.parametrize("level", [1, 2])
+def test_fullsize_fp8_towers_close_to_bf16(level):
+    """BASELINE config 5's fp8 MFMA path at full depth / width against the bf16 path on the same random-init weights.
+    Level 1 (e4m3 operands for the LayerNorm-fed qkv / fc1 GEMMs): the emitted tokens differ by ~1 % RMS (measured
+    1.2e-2) and the segment selection - the integer part of the path - is unchanged; level 2 (out-proj / fc2 too, inputs
+    quantised per row by tdc_quantize_rows_fp8): the towers move by 8.8 % / 24 % RMS (level 1: 5.8 % / 19 %) - e4m3 has
+    3 mantissa bits and random-init weights offer nothing to average the noise against - which is enough to reorder the
+    near-tied adjacent-frame similarities of the synthetic video, so only the towers are compared there."""
     import bench
     import tdc_video_amd  # noqa: F401
     from tdc_video_amd.pipeline import VideoEncoder
@@ -289,17 +292,21 @@ def test_fullsize_fp8_towers_close_to_bf16():
     vs = bench.synth_video(0, T, 384, dev, torch.bfloat16, scene_len=5)
     vd = bench.synth_video(0, T, 378, dev, torch.bfloat16, seed=4321, scene_len=5)
     outs = {}
-    for fp8 in (False, True):
+    for fp8 in (0, level):
         enc = VideoEncoder(sd, cfg, dtype=torch.bfloat16, device=dev, tower_batch=20, fp8_towers=fp8)
-        assert all(bool(t.fp8) == fp8 for t in enc.towers.values())
+        assert all(int(t.fp8) == fp8 for t in enc.towers.values())
         keep = {}
         vis = run(enc, vs, vd, keep)
-        outs[fp8] = (vis.float(), keep["seg_indices"], keep["dino_feat"].float())
+        outs[fp8] = (vis.float(), keep["seg_indices"], keep["dino_feat"].float(), keep["siglip_feat"].float())
         del enc
         torch.cuda.empty_cache()
-    a, b = outs[False][0], outs[True][0]
-    assert outs[False][1] == outs[True][1] and a.shape == b.shape
-    rms = ((a - b).pow(2).mean().sqrt() / a.pow(2).mean().sqrt()).item()
-    rms_d = ((outs[False][2] - outs[True][2]).pow(2).mean().sqrt() / outs[False][2].pow(2).mean().sqrt()).item()
-    print("fp8 vs bf16 at full size: emitted tokens rel RMS %.3e, DINOv2 tower rel RMS %.3e" % (rms, rms_d))
-    assert rms < 4e-2 and rms_d < 0.3
+
+    def rms(i):
+        a, b = outs[0][i], outs[level][i]
+        return ((a - b).pow(2).mean().sqrt() / a.pow(2).mean().sqrt()).item()
+    print("fp8 level %d vs bf16 at full size: DINOv2 tower rel RMS %.3e, SigLIP %.3e" % (level, rms(2), rms(3)))
+    assert rms(2) < (0.3 if level == 1 else 0.4) and rms(3) < (0.1 if level == 1 else 0.15)
+    if level == 1:
+        assert outs[0][1] == outs[1][1] and outs[0][0].shape == outs[1][0].shape
+        print("   emitted tokens rel RMS %.3e" % rms(0))
+        assert rms(0) < 4e-2

@@ -191,6 +191,26 @@ def test_gemm_fp8_operands(ops, dtype, M):
         assert out.dtype == dtype and relerr(out, want) < tol(dtype), act
     # and the quantisation itself is at the e4m3 level (3 mantissa bits) on the linear output
     assert relerr(lin, x @ w.t() + b) < 5e-2
+    # fp32 residual-stream update on fp8 operands (out-projection / fc2 of the fp8 towers), in place
+    r32 = torch.randn(M, N, device="cuda", generator=g)
+    o32 = r32.clone()
+    ops.gemm(x8, w8, b, res=o32, out=o32, out_f32=True, ln_stats=stats, ln_c1=c1, out_dtype=dtype)
+    assert relerr(o32, lin + r32) < 1e-4
+
+
+def test_quantize_rows_fp8(ops):
+    """tdc_quantize_rows_fp8: per-row e4m3 quantisation of a 16-bit matrix (row maximum on 448, zero K padding, stats =
+    (0, s_a * wscale)), equal to torch's e4m3 rounding of the scaled row."""
+    g = torch.Generator(device="cuda").manual_seed(4)
+    for cols, dtype in ((1152, torch.bfloat16), (4304, torch.float16), (4096, torch.bfloat16)):
+        rows, ws = 333, 0.25
+        x = (torch.randn(rows, cols, device="cuda", generator=g) * torch.rand(rows, 1, device="cuda", generator=g) * 5).to(dtype)
+        y8, st = ops.quantize_rows_fp8(x, cols, ws)
+        assert y8.shape == (rows, (cols + 127) // 128 * 128) and torch.count_nonzero(y8[:, cols:]) == 0
+        sa = x.float().abs().amax(1) / 448.0
+        assert ((st[:, 1] / ws - sa).abs() / sa).max().item() < 1e-6 and torch.count_nonzero(st[:, 0]) == 0
+        want = (x.float() / sa[:, None]).to(torch.float8_e4m3fn).view(torch.uint8)
+        assert (want != y8[:, :cols]).float().mean().item() < 1e-3
 
 
 @pytest.mark.parametrize("cols", [1152, 1536])

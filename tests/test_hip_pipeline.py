@@ -135,9 +135,10 @@ def test_towers_natural_scale(kind, D, heads, mlp, px, fuse, dtype, monkeypatch)
     assert rel(got, ref) < (4e-3 if dtype == torch.float16 else 6e-2)  # bf16: 8 mantissa bits on a raw residual stream
 
 
+@pytest.mark.parametrize("level", [1, 2])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("kind,D,heads,mlp,px", [("siglip", 128, 2, 272, 126), ("dino", 256, 4, 344, 126)])
-def test_towers_fp8_operands(kind, D, heads, mlp, px, dtype):
+def test_towers_fp8_operands(kind, D, heads, mlp, px, dtype, level):
     """BASELINE config 5's fp8 MFMA path: the towers' LayerNorms emit e4m3 rows with per-row scales and the qkv / fc1
     GEMMs run on fp8 operands (per-tensor weight scales); HIP vs the fp32 oracle (tolerance: e4m3's 3 mantissa bits on
     two of the four GEMM inputs of every block), and the C++ composite equals the per-kernel sequence bit for bit."""
@@ -155,8 +156,9 @@ def test_towers_fp8_operands(kind, D, heads, mlp, px, dtype):
     enc.dtype, enc.dev, enc.tower_batch = dtype, torch.device("cuda"), 3
     enc._tables = {}
     enc.out_grid = [out_grid, out_grid]
-    t = (Wt.prep_siglip if kind == "siglip" else Wt.prep_dino)(sd, heads, dtype, enc.dev, fp8=True)
-    assert t.fp8 and t.layers[0].qkv.w.dtype == torch.uint8
+    t = (Wt.prep_siglip if kind == "siglip" else Wt.prep_dino)(sd, heads, dtype, enc.dev, fp8=level)
+    assert t.fp8 == level and t.layers[0].qkv.w.dtype == torch.uint8
+    assert (t.layers[0].fc2.w.dtype == torch.uint8) == (level == 2)     # level 2: out-proj / fc2 on fp8 operands too
     enc.towers = {kind: t}
     enc.native_towers = True
     a = enc.tower(kind, pixels.cuda())
@@ -167,10 +169,10 @@ def test_towers_fp8_operands(kind, D, heads, mlp, px, dtype):
     # e4m3 products carry ~2^-4 relative noise each and a random-init tower has no correlated signal to average it
     # against, so the yardstick is the RMS error relative to the RMS of the output (max error: a few sigma of it)
     rms = ((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
-    print("fp8 tower %s D=%d %s: rel RMS err %.3e, max err / max|ref| %.3e" % (kind, D, dtype, rms, rel(got, ref)))
+    print("fp8 level %d tower %s D=%d %s: rel RMS err %.3e, max err / max|ref| %.3e" % (level, kind, D, dtype, rms, rel(got, ref)))
     # measured: SigLIP-like (GELU MLP) 4.6e-2 RMS, DINOv2-like (SwiGLU: a product of two quantised branches, LayerScale,
     # final LayerNorm) 1.4e-1 RMS after 3 random-init layers
-    assert rms < (8e-2 if kind == "siglip" else 2e-1) and rel(got, ref) < 0.35
+    assert rms < (1e-1 if kind == "siglip" else 2.5e-1) and rel(got, ref) < 0.45
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])

@@ -22,7 +22,7 @@ def main():
     vs = bench.synth_video(0, T, 384, dev, torch.bfloat16, scene_len=5)
     vd = bench.synth_video(0, T, 378, dev, torch.bfloat16, seed=4321, scene_len=5)
     outs = {}
-    for fp8 in (False, True):
+    for fp8 in (0, 1, 2):
         enc = VideoEncoder(sd, cfg, dtype=torch.bfloat16, device=dev, tower_batch=20, fp8_towers=fp8)
         keep = {}
         vis = enc.encode_video(vs, vd, (384, 384), budget_text_len=64, n_text_tokens=64,
@@ -30,14 +30,16 @@ def main():
         outs[fp8] = (keep["siglip_feat"].float(), keep["dino_feat"].float(), vis.float(), keep["seg_indices"])
         del enc
         torch.cuda.empty_cache()
-    for name, i in (("siglip tower", 0), ("dino tower", 1), ("emitted tokens", 2)):
-        a, b = outs[False][i], outs[True][i]
-        if a.shape != b.shape:
-            print("%-15s shapes differ %s vs %s" % (name, tuple(a.shape), tuple(b.shape)))
-            continue
-        rms = ((a - b).pow(2).mean().sqrt() / a.pow(2).mean().sqrt()).item()
-        print("%-15s fp8 vs bf16: rel RMS diff %.3e, max diff / max|bf16| %.3e" % (name, rms, ((a - b).abs().max() / a.abs().max()).item()))
-    print("segment selection identical:", outs[False][3] == outs[True][3])
+    for level in (1, 2):
+        for name, i in (("siglip tower", 0), ("dino tower", 1), ("emitted tokens", 2)):
+            a, b = outs[0][i], outs[level][i]
+            if a.shape != b.shape:
+                print("%-15s shapes differ %s vs %s" % (name, tuple(a.shape), tuple(b.shape)))
+                continue
+            rms = ((a - b).pow(2).mean().sqrt() / a.pow(2).mean().sqrt()).item()
+            print("level %d %-15s fp8 vs bf16: rel RMS diff %.3e, max diff / max|bf16| %.3e"
+                  % (level, name, rms, ((a - b).abs().max() / a.abs().max()).item()))
+        print("level %d segment selection identical:" % level, outs[0][3] == outs[level][3])
 
 
 if __name__ == "__main__":
