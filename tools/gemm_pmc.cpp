@@ -24,26 +24,45 @@ static void fill_bf16(std::vector<unsigned short>& v, unsigned seed, float scale
 int main(int argc, char** argv) {
     if (argc < 2) { fprintf(stderr, "usage: gemm_pmc shapes.txt [reps]\n"); return 2; }
     int reps = argc > 2 ? atoi(argv[2]) : 2;
+    const bool fp8 = getenv("TDC_PMC_FP8") != nullptr;      // e4m3 operands (K % 128 == 0 shapes only; others are skipped)
     FILE* f = fopen(argv[1], "r");
     if (!f) { perror("shapes"); return 2; }
     int M, N, K, act, res, outf32, count;
     hipStream_t st; CK(hipStreamCreate(&st));
     while (fscanf(f, "%d %d %d %d %d %d %d", &M, &N, &K, &act, &res, &outf32, &count) == 7) {
+        if (fp8 && (K % 128 != 0 || (outf32 && !res) || act == TDC_ACT_GELU_ERF)) {
+            printf("skip M=%d N=%d K=%d (not an fp8 tower shape)\n", M, N, K);
+            continue;
+        }
         size_t nA = (size_t)M * K, nW = (size_t)N * K, nC = (size_t)M * N;
         std::vector<unsigned short> hA(nA), hW(nW);
         fill_bf16(hA, M + K, 1.0f); fill_bf16(hW, N + K, 0.05f);
         void *A, *W, *C; float* bias;
         CK(hipMalloc(&A, nA * 2)); CK(hipMalloc(&W, nW * 2)); CK(hipMalloc(&C, nC * (outf32 ? 4 : 2))); CK(hipMalloc((void**)&bias, N * 4));
+        if (fp8) {   // random e4m3 bytes without the NaN encodings (0x7f / 0xff), packed two per 16-bit slot
+            unsigned char* a8 = (unsigned char*)hA.data(); unsigned char* w8 = (unsigned char*)hW.data();
+            for (size_t i = 0; i < nA; ++i) if ((a8[i] & 0x7f) == 0x7f) a8[i] &= 0xf7;
+            for (size_t i = 0; i < nW; ++i) if ((w8[i] & 0x7f) == 0x7f) w8[i] &= 0xf7;
+        }
         CK(hipMemcpy(A, hA.data(), nA * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(W, hW.data(), nW * 2, hipMemcpyHostToDevice));
         CK(hipMemset(bias, 0, N * 4)); CK(hipMemset(C, 0, nC * (outf32 ? 4 : 2)));
         tdc_gemm_desc d = {};
         d.A = A; d.lda = K; d.W = W; d.ldw = K; d.C = C; d.ldc = (act == TDC_ACT_SWIGLU) ? N / 2 : N; d.bias = bias;
         d.M = M; d.N = N; d.K = K; d.dtype = TDC_BF16; d.out_f32 = outf32; d.act = act;
         if (res) { d.res = C; d.ldres = N; d.res_f32 = outf32; }   // in-place residual stream update
+        float *stats = nullptr, *c1 = nullptr;
+        if (fp8) {
+            std::vector<float> hs((size_t)M * 2);
+            for (int m = 0; m < M; ++m) { hs[2 * m] = 0.f; hs[2 * m + 1] = 1e-4f; }
+            CK(hipMalloc((void**)&stats, (size_t)M * 8)); CK(hipMalloc((void**)&c1, (size_t)N * 4));
+            CK(hipMemcpy(stats, hs.data(), (size_t)M * 8, hipMemcpyHostToDevice)); CK(hipMemset(c1, 0, (size_t)N * 4));
+            d.in_fp8 = 1; d.ln_stats = stats; d.ln_c1 = c1;
+        }
         for (int r = 0; r < reps; ++r) { int rc = tdc_gemm(&d, st); if (rc) { fprintf(stderr, "tdc_gemm rc=%d\n", rc); return 1; } }
         CK(hipStreamSynchronize(st));
         printf("ran M=%d N=%d K=%d act=%d res=%d outf32=%d x%d\n", M, N, K, act, res, outf32, reps);
         CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(C)); CK(hipFree(bias));
+        if (stats) { CK(hipFree(stats)); CK(hipFree(c1)); }
     }
     return 0;
 }
