@@ -61,8 +61,17 @@ typedef struct {
     const float* ln_stats; const float* ln_c1;
     /* in_fp8 != 0: A and W hold OCP e4m3 bytes (K % 128 == 0, lda / ldw % 16 == 0, both counted in values), accumulated by
      * v_mfma_f32_16x16x128_f8f6f4 (unit block scales); `dtype` stays the 16-bit type of C / res.  The dequantisation scales ride on the
-     * LayerNorm-fold operands: ln_stats[m] = (0, s_a[m] * s_w) and ln_c1 = 0 give C = act(s_a[m] s_w acc + bias). */
+     * LayerNorm-fold operand ln_stats[m] = (*, s_a[m] * s_w): C = act(s_a[m] s_w acc + bias).  ln_c1 is not read (may be NULL)
+     * and ln_stats[m].x is used by out_fp8 only. */
     int in_fp8;
+    /* out_fp8 != 0 (with in_fp8 + ln_stats, no residual, N % 64 == 0): C receives OCP e4m3 bytes [M, ldc] (ldc in bytes,
+     * % 16 == 0) scaled per row by s_h[m] = B[m]^p / 448, where B[m] = ln_stats[m].y * ln_stats[m].x * out_w2max + out_bmax
+     * bounds |A W^T + b| on that row (Cauchy-Schwarz: ln_stats.x = the 2-norm of the quantised A row as tdc_layernorm's
+     * y8 path writes it, out_w2max = the largest 2-norm of a quantised W row, out_bmax = max|bias|) and p = 2 for SWIGLU
+     * (|silu(a) b| <= |a| |b|), 1 otherwise (|gelu(a)| <= |a|).  e4m3 is a floating-point format: a scale that is safe but
+     * an order of magnitude loose costs no relative precision.  out_stats[m] = (0, s_h[m] * out_wscale) are the ln_stats
+     * of the fp8-operand GEMM that consumes C (out_wscale = its per-tensor weight scale). */
+    int out_fp8; float* out_stats; float out_w2max, out_bmax, out_wscale;
 } tdc_gemm_desc;
 int tdc_gemm(const tdc_gemm_desc* d, void* stream);
 /* per-row e4m3 quantisation of a 16-bit matrix x [rows, ldx] (cols % 8 == 0, cols <= 4608): y8 [rows, ldy8] = x / s_a[r]
@@ -89,8 +98,9 @@ typedef struct {
     int rows, cols, dtype;
     tdc_rowmap x_map, y_map; /* row r reads x[x_map(r)] and writes y*[y_map(r)] (identity when seg == 0) */
     /* fp8 output (may be NULL; y16 / y32 may then be NULL too): y8 [rows, ldy8] OCP e4m3 bytes = y / s_a[r] with the
-     * per-row scale s_a[r] = max|y[r]| / 448, pad columns zero; y8_stats[r] = (0, s_a[r] * y8_wscale) is the ln_stats
-     * operand of the fp8-operand tdc_gemm that consumes y8 (y8_wscale = that GEMM's per-tensor weight scale). */
+     * per-row scale s_a[r] = max|y[r]| / 448, pad columns zero; y8_stats[r] = (1.07 ||y[r] / s_a[r]||_2, s_a[r] * y8_wscale) is
+     * the ln_stats operand of the fp8-operand tdc_gemm that consumes y8 (y8_wscale = that GEMM's per-tensor weight scale;
+     * the first entry - an upper bound of the 2-norm of the QUANTISED row - only matters to tdc_gemm_desc.out_fp8). */
     void* y8; int ldy8; float* y8_stats; float y8_wscale;
 } tdc_ln_desc;
 int tdc_layernorm(const tdc_ln_desc* d, void* stream);
@@ -190,6 +200,8 @@ typedef struct {
      * zeros [>= max n] fp32 zeros (the ln_c1 operand of an fp8-operand tdc_gemm) */
     float qkv_wscale, fc1_wscale; const float* zeros;
     float out_wscale, fc2_wscale;    /* fp8 level 2: out.w / fc2.w are e4m3 too */
+    float fc1_w2max, fc1_bmax;       /* fp8 level 3: max row 2-norm of fc1's e4m3 weight (in units of fc1_wscale), max |fc1.b|
+                                        (tdc_gemm_desc.out_w2max / out_bmax) */
 } tdc_vit_layer;
 typedef struct {
     int dtype, dim, heads, head_dim, n_layers, patch, has_cls;
@@ -203,7 +215,9 @@ typedef struct {
     int fused;                       /* pre-LayerNorms folded into the qkv / fc1 GEMMs (dim % 64 == 0) */
     int fp8;                         /* 1: the LayerNorms emit e4m3 rows + per-row scales and the qkv / fc1 GEMMs run on fp8
                                         operands (dim % 128 == 0; excludes `fused`); 2: out-proj / fc2 as well, their inputs
-                                        (attention output, MLP hidden) quantised per row by tdc_quantize_rows_fp8 */
+                                        (attention output, MLP hidden) quantised per row by tdc_quantize_rows_fp8; 3: as 2, but
+                                        fc1 writes the MLP hidden as e4m3 itself (tdc_gemm_desc.out_fp8; needs fc1's output
+                                        width == fc2.k) */
 } tdc_vit_model;
 size_t tdc_vit_workspace_bytes(const tdc_vit_model* m, int B, int H, int W);
 /* px [B,3,H,W] (fp32 when px_f32 else 16-bit) -> out [B*out_grid*out_grid, ldo] 16-bit; idx0/idx1/frac: bilinear tables

@@ -42,7 +42,7 @@ VitWs vit_layout(const tdc_vit_model* m, int B, int H, int W) {
     w.attn = off;    off += al256(rows * Dp * 2);
     w.mlp = off;     off += al256(rows * mlp_w * 2);
     w.part = off;    off += m->fused ? al256(rows * (size_t)(Dp / 64) * 8) : 0;
-    w.stats = off;   off += (m->fused || m->fp8) ? al256(rows * 8) : 0;
+    w.stats = off;   off += (m->fused || m->fp8) ? al256(rows * 8) * (m->fp8 >= 3 ? 2 : 1) : 0;   // level 3: fc1's out_stats
     w.total = off;
     return w;
 }
@@ -87,6 +87,17 @@ int gemm_fp8(const void* A8, int lda, const tdc_lin& L, void* C, int ldc, int M,
     memset(&d, 0, sizeof(d));
     d.A = A8; d.lda = lda; d.W = L.w; d.ldw = L.k; d.C = C; d.ldc = ldc; d.bias = L.b;
     d.M = M; d.N = L.n; d.K = L.k; d.dtype = dtype; d.act = act; d.in_fp8 = 1; d.ln_stats = stats; d.ln_c1 = zeros;
+    return tdc_gemm(&d, st);
+}
+
+// ... with e4m3 output C8 (row stride ldc bytes) + out_stats for the fp8-operand GEMM (weight scale next_wscale) after it
+int gemm_fp8_out8(const void* A8, int lda, const tdc_lin& L, void* C8, int ldc, int M, int dtype, int act, const float* stats,
+                  const float* zeros, float* out_stats, float w2max, float bmax, float next_wscale, void* st) {
+    tdc_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.A = A8; d.lda = lda; d.W = L.w; d.ldw = L.k; d.C = C8; d.ldc = ldc; d.bias = L.b;
+    d.M = M; d.N = L.n; d.K = L.k; d.dtype = dtype; d.act = act; d.in_fp8 = 1; d.ln_stats = stats; d.ln_c1 = zeros;
+    d.out_fp8 = 1; d.out_stats = out_stats; d.out_w2max = w2max; d.out_bmax = bmax; d.out_wscale = next_wscale;
     return tdc_gemm(&d, st);
 }
 
@@ -334,13 +345,21 @@ extern "C" int tdc_vit_fwd(const tdc_vit_model* m, const void* px, int px_f32, i
                 RET_IF(gemm(attn, Dp, L.out, x32, Dp, rows, dt, TDC_ACT_NONE, 1, x32, Dp, 1, ident, ident, stream));
             }
             RET_IF(layernorm_fp8(x32, Dp, h16, L.fc1.k, stats, L.fc1_wscale, L.ln2_g, L.ln2_b, m->eps, rows, D, dt, stream));
-            RET_IF(gemm_fp8(h16, L.fc1.k, L.fc1, mlp, mlp_ld, rows, dt, m->act, stats, L.zeros, stream));
-            if (m->fp8 >= 2) {   // MLP hidden -> e4m3 rows (in the qkv buffer, free after the attention) -> fc2 on fp8
-                const int mlp_n = m->act == TDC_ACT_SWIGLU ? L.fc1.n / 2 : L.fc1.n;   // columns fc1 writes (pad columns: 0)
-                RET_IF(tdc_quantize_rows_fp8(mlp, mlp_ld, rows, mlp_n, dt, qkv, L.fc2.k, stats, L.fc2_wscale, stream));
-                RET_IF(gemm_fp8_rmw(qkv, L.fc2.k, L.fc2, x32, Dp, rows, dt, stats, L.zeros, stream));
+            const int mlp_n = m->act == TDC_ACT_SWIGLU ? L.fc1.n / 2 : L.fc1.n;   // columns fc1 writes (pad columns: 0)
+            if (m->fp8 >= 3) {   // fc1 writes the e4m3 MLP hidden + its row scales itself (qkv buffer, second stats array)
+                float* stats2 = stats + al256((size_t)rows * 8) / 4;
+                if (mlp_n != L.fc2.k) return TDC_E_BADARG;
+                RET_IF(gemm_fp8_out8(h16, L.fc1.k, L.fc1, qkv, L.fc2.k, rows, dt, m->act, stats, L.zeros, stats2, L.fc1_w2max,
+                                     L.fc1_bmax, L.fc2_wscale, stream));
+                RET_IF(gemm_fp8_rmw(qkv, L.fc2.k, L.fc2, x32, Dp, rows, dt, stats2, L.zeros, stream));
             } else {
-                RET_IF(gemm(mlp, L.fc2.k, L.fc2, x32, Dp, rows, dt, TDC_ACT_NONE, 1, x32, Dp, 1, ident, ident, stream));
+                RET_IF(gemm_fp8(h16, L.fc1.k, L.fc1, mlp, mlp_ld, rows, dt, m->act, stats, L.zeros, stream));
+                if (m->fp8 == 2) {   // MLP hidden -> e4m3 rows (in the qkv buffer, free after the attention) -> fc2 on fp8
+                    RET_IF(tdc_quantize_rows_fp8(mlp, mlp_ld, rows, mlp_n, dt, qkv, L.fc2.k, stats, L.fc2_wscale, stream));
+                    RET_IF(gemm_fp8_rmw(qkv, L.fc2.k, L.fc2, x32, Dp, rows, dt, stats, L.zeros, stream));
+                } else {
+                    RET_IF(gemm(mlp, L.fc2.k, L.fc2, x32, Dp, rows, dt, TDC_ACT_NONE, 1, x32, Dp, 1, ident, ident, stream));
+                }
             }
         } else {
             RET_IF(gemm(attn, Dp, L.out, x32, Dp, rows, dt, TDC_ACT_NONE, 1, x32, Dp, 1, ident, ident, stream));

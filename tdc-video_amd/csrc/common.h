@@ -83,13 +83,30 @@ __device__ __forceinline__ float erf_as(float x) {
 }
 // nn.GELU() / ACT2FN["gelu"]: 0.5 x (1 + erf(x / sqrt(2)))
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
-// "gelu_pytorch_tanh": 0.5 x (1 + tanh(u)) == x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3)   (exact identity)
-__device__ __forceinline__ float gelu_tanh(float x) {
-    const float k2 = 2.0f * 0.7978845608028654f * 1.4426950408889634f;  // 2 sqrt(2/pi) log2(e)
-    const float u = x * __builtin_fmaf(0.044715f * x, x, 1.0f);
-    return x * fast_rcp(1.0f + fast_exp2(-k2 * u));
+// "gelu_pytorch_tanh": 0.5 x (1 + tanh(u)) == x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3)   (exact identity),
+// as x / (1 + 2^(x (c0 + c1 x^2))).  The GEMM epilogues are VALU-bound on this, so the arithmetic around the two
+// transcendentals is written on float pairs (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: two lanes' worth per issue).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_tanh2(f32x2_t x) {
+    const float c0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;  // -2 sqrt(2/pi) log2(e)
+    const float c1 = c0 * 0.044715f;
+    const f32x2_t z = x * __builtin_elementwise_fma(x * x, (f32x2_t){c1, c1}, (f32x2_t){c0, c0});
+    const f32x2_t d = (f32x2_t){fast_exp2(z[0]), fast_exp2(z[1])} + 1.0f;
+    return x * (f32x2_t){fast_rcp(d[0]), fast_rcp(d[1])};
+}
+__device__ __forceinline__ float gelu_tanh(float x) { return gelu_tanh2((f32x2_t){x, x})[0]; }
+__device__ __forceinline__ f32x4 gelu_tanh4(f32x4 v) {
+    const f32x2_t a = gelu_tanh2((f32x2_t){v[0], v[1]}), b = gelu_tanh2((f32x2_t){v[2], v[3]});
+    return (f32x4){a[0], a[1], b[0], b[1]};
 }
 __device__ __forceinline__ float silu(float x) { return x * fast_rcp(1.0f + fast_exp2(-1.4426950408889634f * x)); }
+// SwiGLU on interleaved (gate, up) columns: (silu(v0) v1, silu(v2) v3)
+__device__ __forceinline__ f32x2_t swiglu2(f32x4 v) {
+    const f32x2_t gate = {v[0], v[2]}, up = {v[1], v[3]};
+    const f32x2_t z = gate * -1.4426950408889634f;
+    const f32x2_t d = (f32x2_t){fast_exp2(z[0]), fast_exp2(z[1])} + 1.0f;
+    return gate * (f32x2_t){fast_rcp(d[0]), fast_rcp(d[1])} * up;
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -44,11 +44,16 @@ extern "C" int tdc_gemm(const tdc_gemm_desc* d, void* stream) {
                             update (identity row maps); row statistics indexed by the A / C row */
         const bool rmw = d->in_fp8 && d->out_f32 && d->res && d->res_f32 && d->act == TDC_ACT_NONE && !d->x16 &&
                          d->c_map.seg == 0 && d->r_map.seg == 0;
-        if (!d->ln_c1 || (!rmw && (d->out_f32 || d->res)) || d->a_map.seg != 0 || ((uintptr_t)d->ln_stats & 7) ||
+        if ((!d->ln_c1 && !d->in_fp8) || (!rmw && (d->out_f32 || d->res)) || d->a_map.seg != 0 || ((uintptr_t)d->ln_stats & 7) ||
             ((uintptr_t)d->ln_c1 & 15))
             return TDC_E_BADARG;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (d->out_fp8) {    /* e4m3 output: fp8 operands with their scales, whole 64-column wave tiles, 16-byte rows */
+        if (!d->in_fp8 || !d->ln_stats || !d->out_stats || d->out_f32 || d->res || d->c_map.seg != 0 || d->N % 64 != 0 ||
+            (d->ldc & 15) || ((uintptr_t)d->C & 15) || ((uintptr_t)d->out_stats & 7) || !(d->out_w2max > 0.f))
+            return TDC_E_BADARG;
+    }
     if (d->in_fp8) return tdc_gemm_fp8_impl(d, st);
     if (d->dtype == TDC_F16) return launch<f16, false>(d, st);
     if (d->dtype == TDC_BF16) return launch<bf16, false>(d, st);

@@ -23,6 +23,8 @@ struct GemmArgs {
     // LayerNorm fusion (see EpiOps / slot_stats_*): producer side x16 + ln_part, consumer side ln_stats + ln_c1
     void* x16; int ldx16; float* ln_part;
     const float* ln_stats; const float* ln_c1;
+    // e4m3 output with analytic per-row scales (tdc_gemm_desc.out_fp8; fp8 operands + LayerNorm-fold operands only)
+    int out_fp8; float* out_stats; float out_w2max, out_bmax, out_wscale;
 #ifdef TDC_GEMM_DIAG
     unsigned long long* stamps;   // diagnostics build only (tools/gemm_stamps.cpp): 8 x u64 per workgroup
 #endif
@@ -67,6 +69,14 @@ __device__ __forceinline__ float lane_get(float v, int src_lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane * 4, __builtin_bit_cast(int, v)));
 }
 
+// fp8 operands (gemm_fp8.hip's instantiations): the fold carries only the dequantisation scale rstd = s_a s_w - ln_c1 is
+// not read and the first fma is gone (this epilogue is VALU-bound); `mean` is the row-norm bound out_fp8 uses.
+#ifdef TDC_GEMM_FP8_TU
+constexpr bool kScaleOnly = true;
+#else
+constexpr bool kScaleOnly = false;
+#endif
+
 template <int MI, int NJ, bool LANE, bool FOLD>
 struct EpiOps {
     f32x4 bias[NJ], c1[NJ];
@@ -78,7 +88,7 @@ struct EpiOps {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     bias[j][e] = lane_get(el.bias, j * 16 + g * 4 + e);
-                    if (FOLD) c1[j][e] = lane_get(el.c1, j * 16 + g * 4 + e);
+                    if (FOLD && !kScaleOnly) c1[j][e] = lane_get(el.c1, j * 16 + g * 4 + e);
                 }
             } else {
                 const int n = nbase + j * 16 + g * 4;
@@ -86,7 +96,7 @@ struct EpiOps {
                 if (FOLD) c1[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (n < p.N) {
                     if (p.bias) bias[j] = *(const f32x4*)(p.bias + n);
-                    if (FOLD) c1[j] = *(const f32x4*)(p.ln_c1 + n);
+                    if (FOLD && !kScaleOnly) c1[j] = *(const f32x4*)(p.ln_c1 + n);
                 }
             }
         }
@@ -113,7 +123,8 @@ struct EpiOps {
         f32x4 r;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            r[e] = __builtin_fmaf(rstd[i], __builtin_fmaf(-mean[i], c1[j][e], acc[e]), bias[j][e]);
+            r[e] = kScaleOnly ? __builtin_fmaf(rstd[i], acc[e], bias[j][e])
+                              : __builtin_fmaf(rstd[i], __builtin_fmaf(-mean[i], c1[j][e], acc[e]), bias[j][e]);
         return r;
     }
 };
@@ -178,11 +189,11 @@ __device__ __forceinline__ void epi_store(const GemmArgs& p, f32x4 v, long long 
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
     } else if (ACT == TDC_ACT_GELU_TANH) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+        v = gelu_tanh4(v);
     } else if (ACT == TDC_ACT_SWIGLU) {
         // columns are interleaved (x1_j, x2_j): two outputs per lane at column n/2
-        const float o0 = silu(v[0]) * v[1], o1 = silu(v[2]) * v[3];
+        const f32x2_t sg = swiglu2(v);
+        const float o0 = sg[0], o1 = sg[1];
         const int nc = n >> 1;
         if (OUTF32) {
             float* c = (float*)p.C + crow * p.ldc + nc;
@@ -267,10 +278,81 @@ __device__ __forceinline__ void epi_tile_emit(const GemmArgs& p, f32x4 (&acc)[MI
     }
 }
 
+// ---- e4m3 output with analytic per-row scales (tdc_gemm_desc.out_fp8) -----------------------------------------------------
+// Row m of act(A W^T + b) is bounded by B = rstd * ||a8||_2 * max_n ||w8_n||_2 + max|b| (Cauchy-Schwarz on the quantised
+// operands; ops.mean carries the row norm, ops.rstd the row's s_a * s_w), squared for SwiGLU; the row goes out as
+// e4m3(v * 448 / B^p).  A loose bound costs nothing: e4m3 keeps its 3 mantissa bits over 15 binades.
+template <int MI, int NJ, bool LB, bool SW>
+struct RowScale8 {
+    float inv[MI], out[MI];
+    __device__ __forceinline__ void set(const GemmArgs& p, const EpiOps<MI, NJ, LB, true>& ops) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            float b = __builtin_fmaf(ops.rstd[i] * ops.mean[i], p.out_w2max, p.out_bmax);
+            if (SW) b = b * b;
+            b = fmaxf(b, 1e-30f);
+            inv[i] = 448.0f / b;
+            out[i] = b * (1.0f / 448.0f) * p.out_wscale;
+        }
+    }
+};
+__device__ __forceinline__ int pack_fp8x4(f32x4 v) {
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+    return __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+}
+__device__ __forceinline__ f32x4 act4(f32x4 v, int act) {
+    if (act == TDC_ACT_GELU_ERF) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+    } else if (act == TDC_ACT_GELU_TANH) {
+        v = gelu_tanh4(v);
+    }
+    return v;
+}
+
+// MFMA-layout form (128^2 kernel, fallback): 4 bytes (2 for SwiGLU) per lane and accumulator tile
+template <class T, int MI, int NJ, int ACT, bool LB>
+__device__ __forceinline__ void epi_tile8(const GemmArgs& p, f32x4 (&acc)[MI][NJ], int mbase, int nbase, int fr, int g,
+                                          const EpiLane& el) {
+    EpiOps<MI, NJ, LB, true> ops;
+    ops.load(p, mbase, nbase, fr, g, el);
+    RowScale8<MI, NJ, LB, ACT == TDC_ACT_SWIGLU> rs;
+    rs.set(p, ops);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = mbase + i * 16 + fr;
+        if (m >= p.M) continue;
+        unsigned char* crow = (unsigned char*)p.C + (long long)m * p.ldc;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = nbase + j * 16 + g * 4;
+            if (n >= p.N) continue;
+            const f32x4 v = ops.lin(acc[i][j], i, j);
+            if (ACT == TDC_ACT_SWIGLU) {
+                const f32x2_t sg = swiglu2(v) * rs.inv[i];
+                const int w = __builtin_amdgcn_cvt_pk_fp8_f32(sg[0], sg[1], 0, false);
+                *(unsigned short*)(crow + (n >> 1)) = (unsigned short)w;
+            } else {
+                *(int*)(crow + n) = pack_fp8x4(act4(v, ACT) * rs.inv[i]);
+            }
+        }
+        if (nbase == 0 && g == 0) *(float2*)(p.out_stats + 2 * (long long)m) = make_float2(0.f, rs.out[i]);
+    }
+}
+
 template <class T, int MI, int NJ, bool LB, bool FOLD>
 __device__ __forceinline__ void epilogue_f(const GemmArgs& p, f32x4 (&acc)[MI][NJ], int mbase, int nbase, int fr, int g,
                                            const EpiLane& el) {
     const int res = p.res ? (p.res_f32 ? 1 : 2) : 0;
+    if constexpr (FOLD) {
+        if (p.out_fp8) {
+            if (p.act == TDC_ACT_GELU_ERF) epi_tile8<T, MI, NJ, TDC_ACT_GELU_ERF, LB>(p, acc, mbase, nbase, fr, g, el);
+            else if (p.act == TDC_ACT_GELU_TANH) epi_tile8<T, MI, NJ, TDC_ACT_GELU_TANH, LB>(p, acc, mbase, nbase, fr, g, el);
+            else if (p.act == TDC_ACT_SWIGLU) epi_tile8<T, MI, NJ, TDC_ACT_SWIGLU, LB>(p, acc, mbase, nbase, fr, g, el);
+            else epi_tile8<T, MI, NJ, TDC_ACT_NONE, LB>(p, acc, mbase, nbase, fr, g, el);
+            return;
+        }
+    }
     if (p.act == TDC_ACT_GELU_ERF) epi_tile<T, MI, NJ, TDC_ACT_GELU_ERF, 0, false, LB, FOLD>(p, acc, mbase, nbase, fr, g, el);
     else if (p.act == TDC_ACT_GELU_TANH) epi_tile<T, MI, NJ, TDC_ACT_GELU_TANH, 0, false, LB, FOLD>(p, acc, mbase, nbase, fr, g, el);
     else if (p.act == TDC_ACT_SWIGLU) epi_tile<T, MI, NJ, TDC_ACT_SWIGLU, 0, false, LB, FOLD>(p, acc, mbase, nbase, fr, g, el);
@@ -441,8 +523,7 @@ __device__ __forceinline__ void epi_staged16(const GemmArgs& p, f32x4 (&acc)[8][
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
                 } else if (ACT == TDC_ACT_GELU_TANH) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+                    v = gelu_tanh4(v);
                 }
                 if (RES == 2) {   // 16-bit residual: add before the single rounding to T
                     const int n = nbase + j * 16 + g * 4;
@@ -492,8 +573,9 @@ __device__ __forceinline__ void epi_staged_swiglu(const GemmArgs& p, f32x4 (&acc
             for (int j = 0; j < 4; ++j) {
                 const f32x4 v = ops.lin(acc[i][j], i, j);
                 v2 o;
-                o[0] = (T)(silu(v[0]) * v[1]);
-                o[1] = (T)(silu(v[2]) * v[3]);
+                const f32x2_t sg = swiglu2(v);
+                o[0] = (T)sg[0];
+                o[1] = (T)sg[1];
                 // output column within the wave's 32: j*8 + 2g -> 16-B chunk j (4 per row), swizzled with the row
                 const int chunk = j ^ ((r >> 2) & 3);
                 *(v2*)(region + r * 64 + chunk * 16 + g * 4) = o;
@@ -506,6 +588,78 @@ __device__ __forceinline__ void epi_staged_swiglu(const GemmArgs& p, f32x4 (&acc
             const int m = mbase + pass * ROWS + r, nc = (nbase >> 1) + k * 8;
             if (m < p.M && 2 * nc < p.N) __builtin_nontemporal_store(val, (v8*)((T*)p.C + p.cm(m) * p.ldc + nc));
         }
+    }
+}
+
+// e4m3 output (out_fp8), staged: 4 bytes per lane and accumulator tile -> 64-byte rows of the wave's 128x64 sub-tile (the
+// geometry of the SwiGLU staging: 16-B chunk j of row r at j ^ ((r >> 2) & 3)); read back 16 rows x 64 B per instruction.
+// ROWS = rows per pass: 128 (8 KiB of the 16-KiB region) or 64 (4 KiB).
+template <class T, int ACT, int ROWS, bool LB>
+__device__ __forceinline__ void epi_staged8(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase, int nbase,
+                                            int lane, const EpiLane& el) {
+    const int fr = lane & 15, g = lane >> 4;
+    EpiOps<8, 4, LB, true> ops;
+    ops.load(p, mbase, nbase, fr, g, el);
+    RowScale8<8, 4, LB, false> rs;
+    rs.set(p, ops);
+#pragma unroll
+    for (int pass = 0; pass < 128 / ROWS; ++pass) {
+#pragma unroll
+        for (int ii = 0; ii < ROWS / 16; ++ii) {
+            const int i = pass * (ROWS / 16) + ii;
+            const int r = ii * 16 + fr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int chunk = j ^ ((r >> 2) & 3);
+                *(int*)(region + r * 64 + chunk * 16 + g * 4) = pack_fp8x4(act4(ops.lin(acc[i][j], i, j), ACT) * rs.inv[i]);
+            }
+            if (nbase == 0 && g == 0) {
+                const int m = mbase + i * 16 + fr;
+                if (m < p.M) *(float2*)(p.out_stats + 2 * (long long)m) = make_float2(0.f, rs.out[i]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < ROWS / 16; ++q) {
+            const int r = q * 16 + (lane >> 2), k = lane & 3;
+            const u32x4 val = *(const u32x4*)(region + r * 64 + ((k ^ ((r >> 2) & 3)) << 4));
+            const int m = mbase + pass * ROWS + r, n = nbase + k * 16;
+            if (m < p.M && n < p.N) __builtin_nontemporal_store(val, (u32x4*)((unsigned char*)p.C + (long long)m * p.ldc + n));
+        }
+    }
+}
+
+// ... SwiGLU: 2 bytes per lane and accumulator tile -> 32-byte rows (4 KiB for the whole sub-tile), read back 32 rows x 32 B
+template <class T, bool LB>
+__device__ __forceinline__ void epi_staged8_swiglu(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase, int nbase,
+                                                   int lane, const EpiLane& el) {
+    const int fr = lane & 15, g = lane >> 4;
+    EpiOps<8, 4, LB, true> ops;
+    ops.load(p, mbase, nbase, fr, g, el);
+    RowScale8<8, 4, LB, true> rs;
+    rs.set(p, ops);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = i * 16 + fr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 v = ops.lin(acc[i][j], i, j);
+            const f32x2_t sg = swiglu2(v) * rs.inv[i];
+            const int w = __builtin_amdgcn_cvt_pk_fp8_f32(sg[0], sg[1], 0, false);
+            // output columns j*8 + 2g, +1 of the wave's 32: 16-B half (j >> 1) of the 32-byte row, swizzled with the row
+            const int half = (j >> 1) ^ ((r >> 3) & 1);
+            *(unsigned short*)(region + r * 32 + half * 16 + (j & 1) * 8 + g * 2) = (unsigned short)w;
+        }
+        if (nbase == 0 && g == 0) {
+            const int m = mbase + r;
+            if (m < p.M) *(float2*)(p.out_stats + 2 * (long long)m) = make_float2(0.f, rs.out[i]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = q * 32 + (lane >> 1), k = lane & 1;
+        const u32x4 val = *(const u32x4*)(region + r * 32 + ((k ^ ((r >> 3) & 1)) << 4));
+        const int m = mbase + r, nc = (nbase >> 1) + k * 16;
+        if (m < p.M && 2 * nc < p.N) __builtin_nontemporal_store(val, (u32x4*)((unsigned char*)p.C + (long long)m * p.ldc + nc));
     }
 }
 
@@ -582,6 +736,16 @@ __device__ __forceinline__ bool epilogue_staged_f(const GemmArgs& p, f32x4 (&acc
                                                   int nbase, int lane, const EpiLane& el) {
     const int res = p.res ? (p.res_f32 ? 1 : 2) : 0;
     constexpr int R16 = SMALL ? 32 : 128, RSW = SMALL ? 64 : 128, R32 = SMALL ? 16 : 64;
+    if constexpr (FOLD) {
+        if (p.out_fp8) {           // e4m3 output with analytic per-row scales (host-checked alignment, whole wave tiles)
+            constexpr int R8 = SMALL ? 64 : 128;
+            if (p.act == TDC_ACT_SWIGLU) epi_staged8_swiglu<T, SMALL>(p, acc, region, mbase, nbase, lane, el);
+            else if (p.act == TDC_ACT_GELU_TANH) epi_staged8<T, TDC_ACT_GELU_TANH, R8, SMALL>(p, acc, region, mbase, nbase, lane, el);
+            else if (p.act == TDC_ACT_GELU_ERF) epi_staged8<T, TDC_ACT_GELU_ERF, R8, SMALL>(p, acc, region, mbase, nbase, lane, el);
+            else epi_staged8<T, TDC_ACT_NONE, R8, SMALL>(p, acc, region, mbase, nbase, lane, el);
+            return true;
+        }
+    }
     if (FOLD && p.out_f32 && res == 1 && p.act == TDC_ACT_NONE) {      // fp8 operands of a residual-stream GEMM
         epi_staged32<T, 1, R32, SMALL, false, true>(p, acc, region, mbase, nbase, lane, el);
         return true;
@@ -986,7 +1150,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
         if (n > p.N - 1) n = p.N - 1;
         if (p.bias) e.bias = p.bias[n];
         if (LNF) {
-            e.c1 = p.ln_c1[n];
+            if (!kScaleOnly) e.c1 = p.ln_c1[n];
             int r0 = m0_ + wm * 128 + lane, r1 = r0 + 64;
             if (r0 > p.M - 1) r0 = p.M - 1;
             if (r1 > p.M - 1) r1 = p.M - 1;
@@ -1137,6 +1301,8 @@ int launch(const tdc_gemm_desc* d, hipStream_t st) {
     if (FP8) { a.lda /= 2; a.ldw /= 2; a.K /= 2; }     // kernels address A / W in 2-byte units
     a.out_f32 = d->out_f32; a.res_f32 = d->res_f32; a.act = d->act;
     a.x16 = d->x16; a.ldx16 = d->ldx16; a.ln_part = d->ln_part; a.ln_stats = d->ln_stats; a.ln_c1 = d->ln_c1;
+    a.out_fp8 = d->out_fp8; a.out_stats = d->out_stats; a.out_w2max = d->out_w2max; a.out_bmax = d->out_bmax;
+    a.out_wscale = d->out_wscale;
     { const char* e = getenv("TDC_GEMM_DEBUG"); a.debug = e ? atoi(e) : 0; }
 #ifdef TDC_GEMM_DIAG
     a.stamps = tdc_gemm_diag_stamps;
@@ -1156,7 +1322,7 @@ int launch(const tdc_gemm_desc* d, hipStream_t st) {
         // persistent form: more tiles than CUs, identity a_map, K >= 128, in-tile byte offsets fit 32 bits
         // (the LayerNorm-fold instance only carries the LDS-staged epilogues)
         const int G = persistent_grid();
-        const bool fold_ok = !d->ln_stats || (d->out_f32 && d->res && d->res_f32 && d->act == TDC_ACT_NONE) ||
+        const bool fold_ok = !d->ln_stats || d->out_fp8 || (d->out_f32 && d->res && d->res_f32 && d->act == TDC_ACT_NONE) ||
                              (!d->out_f32 && !(d->ldc & 7) && !((uintptr_t)d->C & 15) &&
                               d->N % (d->act == TDC_ACT_SWIGLU ? 16 : 8) == 0);
         if (G > 0 && a.tiles_m * a.tiles_n > G && d->a_map.seg == 0 && a.K >= 128 && fold_ok &&

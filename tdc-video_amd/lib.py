@@ -21,7 +21,9 @@ class GemmDesc(C.Structure):
                 ("dtype", C.c_int), ("out_f32", C.c_int), ("res_f32", C.c_int), ("act", C.c_int),
                 ("a_map", RowMap), ("c_map", RowMap), ("r_map", RowMap),
                 ("x16", C.c_void_p), ("ldx16", C.c_int), ("ln_part", C.c_void_p),
-                ("ln_stats", C.c_void_p), ("ln_c1", C.c_void_p), ("in_fp8", C.c_int)]
+                ("ln_stats", C.c_void_p), ("ln_c1", C.c_void_p), ("in_fp8", C.c_int),
+                ("out_fp8", C.c_int), ("out_stats", C.c_void_p), ("out_w2max", C.c_float), ("out_bmax", C.c_float),
+                ("out_wscale", C.c_float)]
 
 
 class LnDesc(C.Structure):
@@ -72,7 +74,8 @@ class VitLayer(C.Structure):
                 ("qkv", Lin), ("out", Lin), ("fc1", Lin), ("fc2", Lin),
                 ("qkv_c1", C.c_void_p), ("fc1_c1", C.c_void_p),
                 ("qkv_wscale", C.c_float), ("fc1_wscale", C.c_float), ("zeros", C.c_void_p),
-                ("out_wscale", C.c_float), ("fc2_wscale", C.c_float)]
+                ("out_wscale", C.c_float), ("fc2_wscale", C.c_float),
+                ("fc1_w2max", C.c_float), ("fc1_bmax", C.c_float)]
 
 
 class VitModel(C.Structure):

@@ -81,12 +81,14 @@ FP8_DTYPES = (torch.uint8, torch.float8_e4m3fn)
 
 
 def gemm(a, w, bias=None, act=L.ACT_NONE, res=None, out=None, out_f32=False, M=None, a_map=None, c_map=None,
-         r_map=None, out_rows=None, x16=None, ln_part=None, ln_stats=None, ln_c1=None, out_dtype=None):
+         r_map=None, out_rows=None, x16=None, ln_part=None, ln_stats=None, ln_c1=None, out_dtype=None, out_stats=None,
+         out_w2max=0.0, out_bmax=0.0, out_wscale=1.0):
     """out[c_map(m)] = act(a[a_map(m)] @ w.T + bias) + res[r_map(m)].  a [Ra, lda], w [N, K] (both 16-bit).
     LayerNorm fusion (include/tdc_hip.h): x16 / ln_part = producer outputs (16-bit copy of the fp32 result, per-slot
     (mean, M2) partials [N/64, M, 2]); ln_stats [M, 2] / ln_c1 [N] = consumer inputs (a = raw rows, w = folded weight).
     fp8: a and w hold OCP e4m3 bytes (uint8 / float8_e4m3fn tensors); `out_dtype` names the 16-bit output type and the
-    dequantisation scales come in through ln_stats[m] = (0, s_a[m] * s_w), ln_c1 = 0."""
+    dequantisation scales come in through ln_stats[m] = (row norm bound, s_a[m] * s_w), ln_c1 = 0.  out_stats [M, 2]
+    (with `out` an e4m3 byte tensor): the output leaves as e4m3 with analytic per-row scales (tdc_gemm_desc.out_fp8)."""
     _chk2d(a, "a"); _chk2d(w, "w")
     N, K = w.shape
     fp8 = a.dtype in FP8_DTYPES
@@ -103,10 +105,16 @@ def gemm(a, w, bias=None, act=L.ACT_NONE, res=None, out=None, out_f32=False, M=N
     n_out = N // 2 if act == L.ACT_SWIGLU else N
     if out is None:
         rows = out_rows if out_rows is not None else M
-        out = torch.empty(rows, n_out, device=a.device, dtype=torch.float32 if out_f32 else out_dtype)
+        out = torch.empty(rows, n_out, device=a.device,
+                          dtype=torch.uint8 if out_stats is not None else torch.float32 if out_f32 else out_dtype)
     _chk2d(out, "out")
     assert out.shape[1] >= n_out and _map_max(c_map, M) < out.shape[0], "out too small"
-    assert (out.dtype == torch.float32) == bool(out_f32)
+    out8 = out_stats is not None
+    if out8:
+        assert fp8 and out.dtype in FP8_DTYPES and res is None and not out_f32 and c_map is None
+        assert out_stats.dtype == torch.float32 and out_stats.is_contiguous() and out_stats.numel() >= 2 * M
+    else:
+        assert (out.dtype == torch.float32) == bool(out_f32)
     d = L.GemmDesc()
     d.A, d.lda = a.data_ptr(), a.stride(0)
     d.W, d.ldw = w.data_ptr(), w.stride(0)
@@ -136,6 +144,9 @@ def gemm(a, w, bias=None, act=L.ACT_NONE, res=None, out=None, out_f32=False, M=N
         assert ln_stats.dtype == torch.float32 and ln_stats.is_contiguous() and ln_stats.numel() >= 2 * M
         assert ln_c1.dtype == torch.float32 and ln_c1.is_contiguous() and ln_c1.numel() >= N
         d.ln_stats, d.ln_c1 = ln_stats.data_ptr(), ln_c1.data_ptr()
+    if out8:
+        d.out_fp8, d.out_stats = 1, out_stats.data_ptr()
+        d.out_w2max, d.out_bmax, d.out_wscale = float(out_w2max), float(out_bmax), float(out_wscale)
     e0 = _prof_begin("gemm")
     L.check(L.load().tdc_gemm(C.byref(d), _stream()), "tdc_gemm")
     if e0 is not None:

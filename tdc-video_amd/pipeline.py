@@ -75,14 +75,18 @@ class VideoEncoder:
         def lin(l):
             return L.Lin(l.w.data_ptr(), l.b.data_ptr() if l.b is not None else None, l.w.shape[0], l.w.shape[1])
         layers = (L.VitLayer * len(t.layers))()
+        zeros = None
+        if t.get("fp8"):    # one zero ln_c1 vector long enough for every lin of the tower (tdc_vit_layer.zeros)
+            zn = max(l.w.shape[0] for Lr in t.layers for l in (Lr.qkv, Lr.out, Lr.fc1, Lr.fc2))
+            zeros = t.setdefault("_zeros", torch.zeros(zn, dtype=torch.float32, device=self.dev))
         for i, Lr in enumerate(t.layers):
             layers[i] = L.VitLayer(Lr.ln1_g.data_ptr(), Lr.ln1_b.data_ptr(), Lr.ln2_g.data_ptr(), Lr.ln2_b.data_ptr(),
                                    lin(Lr.qkv), lin(Lr.out), lin(Lr.fc1), lin(Lr.fc2),
                                    Lr.qkv_c1.data_ptr() if Lr.qkv_c1 is not None else None,
                                    Lr.fc1_c1.data_ptr() if Lr.fc1_c1 is not None else None,
                                    Lr.qkv.wscale or 0.0, Lr.fc1.wscale or 0.0,
-                                   Lr.fc1.zeros.data_ptr() if Lr.fc1.zeros is not None else None,
-                                   Lr.out.wscale or 0.0, Lr.fc2.wscale or 0.0)
+                                   zeros.data_ptr() if zeros is not None else None,
+                                   Lr.out.wscale or 0.0, Lr.fc2.wscale or 0.0, Lr.fc1.w2max, Lr.fc1.bmax)
         m = L.VitModel()
         m.dtype = ops._dtcode(self.dtype)
         m.dim, m.heads, m.head_dim, m.n_layers, m.patch, m.has_cls = t.dim, t.heads, t.head_dim, len(t.layers), t.patch, \
@@ -164,6 +168,8 @@ class VideoEncoder:
             mlp_n = t.layers[0].fc1.w.shape[0] // (2 if t.act == "swiglu" else 1)
             mlp_w = max(mlp_w, m8.shape[1])
             mlp = torch.empty(B * S, mlp_w, device=dev, dtype=dt)
+        if fp8 >= 3:    # ... the hidden written as e4m3 by fc1 itself, with its row scales in stats2
+            stats2 = torch.empty(B * S, 2, device=dev, dtype=torch.float32)
         for li, Lr in enumerate(t.layers):
             if fp8:
                 ops.layernorm(x32, Lr.ln1_g, Lr.ln1_b, t.eps, D, dt, y8=h8, y8_stats=stats, y8_wscale=Lr.qkv.wscale)
@@ -187,11 +193,18 @@ class VideoEncoder:
                 ops.gemm(h16, Lr.fc1.w, Lr.fc1.b, act=act, out=mlp, ln_stats=stats, ln_c1=Lr.fc1_c1)
             elif fp8:
                 ops.layernorm(x32, Lr.ln2_g, Lr.ln2_b, t.eps, D, dt, y8=h8, y8_stats=stats, y8_wscale=Lr.fc1.wscale)
-                ops.gemm(h8, Lr.fc1.w, Lr.fc1.b, act=act, out=mlp, ln_stats=stats, ln_c1=Lr.fc1.zeros, out_dtype=dt)
+                if fp8 >= 3:
+                    ops.gemm(h8, Lr.fc1.w, Lr.fc1.b, act=act, out=m8, ln_stats=stats, ln_c1=Lr.fc1.zeros, out_dtype=dt,
+                             out_stats=stats2, out_w2max=Lr.fc1.w2max, out_bmax=Lr.fc1.bmax, out_wscale=Lr.fc2.wscale)
+                else:
+                    ops.gemm(h8, Lr.fc1.w, Lr.fc1.b, act=act, out=mlp, ln_stats=stats, ln_c1=Lr.fc1.zeros, out_dtype=dt)
             else:
                 ops.layernorm(x32, Lr.ln2_g, Lr.ln2_b, t.eps, D, dt, y16=h16)
                 ops.gemm(h16, Lr.fc1.w, Lr.fc1.b, act=act, out=mlp)
-            if fp8 >= 2:
+            if fp8 >= 3:
+                ops.gemm(m8, Lr.fc2.w, Lr.fc2.b, res=x32, out=x32, out_f32=True, ln_stats=stats2, ln_c1=Lr.fc2.zeros,
+                         out_dtype=dt)
+            elif fp8 == 2:
                 ops.quantize_rows_fp8(mlp, mlp_n, Lr.fc2.wscale, y8=m8, stats=stats)
                 ops.gemm(m8, Lr.fc2.w, Lr.fc2.b, res=x32, out=x32, out_f32=True, ln_stats=stats, ln_c1=Lr.fc2.zeros,
                          out_dtype=dt)

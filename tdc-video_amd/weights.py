@@ -21,9 +21,10 @@ def pad64(n):
 
 class Lin:
     """Prepared nn.Linear: w [n_pad, k_pad] 16-bit, b fp32 [n_pad] or None."""
-    __slots__ = ("w", "b", "n", "k", "wscale", "zeros")
+    __slots__ = ("w", "b", "n", "k", "wscale", "zeros", "w2max", "bmax")
 
-    def __init__(self, w, b, n, k, wscale=None, zeros=None):
+    def __init__(self, w, b, n, k, wscale=None, zeros=None, w2max=0.0, bmax=0.0):
+        self.w2max, self.bmax = w2max, bmax         # fp8 weights: max row 2-norm of w (e4m3 units), max |b| (out_fp8 bound)
         self.w, self.b, self.n, self.k = w, b, n, k
         self.wscale, self.zeros = wscale, zeros     # fp8 weights (to_fp8): per-tensor scale, zero ln_c1 vector
 
@@ -83,18 +84,30 @@ def to_fp8(lin, dev):
     sw = amax / 448.0 if amax > 0 else 1.0
     n_pad, k_pad = W.shape[0], (W.shape[1] + 127) // 128 * 128
     W8 = torch.zeros(n_pad, k_pad, dtype=torch.uint8, device=W.device)
-    W8[:, : W.shape[1]] = (W / sw).to(torch.float8_e4m3fn).view(torch.uint8)
+    Wq = (W / sw).to(torch.float8_e4m3fn)
+    W8[:, : W.shape[1]] = Wq.view(torch.uint8)
+    w2max = float(Wq.float().norm(dim=1).max())
+    bmax = float(lin.b.abs().max()) if lin.b is not None else 0.0
     W8 = W8.to(dev).contiguous()
     W8._real_nk = getattr(lin.w, "_real_nk", (lin.n, lin.k))
-    return Lin(W8, lin.b, lin.n, lin.k, wscale=sw, zeros=torch.zeros(n_pad, dtype=torch.float32, device=dev))
+    return Lin(W8, lin.b, lin.n, lin.k, wscale=sw, zeros=torch.zeros(n_pad, dtype=torch.float32, device=dev),
+               w2max=w2max, bmax=bmax)
 
 
 def fp8_enabled(dim, requested):
     """fp8 (e4m3) operand level of a tower of width `dim` (whole 128-byte K tiles only): 0 = none, 1 = the GEMMs fed by a
     LayerNorm (qkv, fc1: the LayerNorm kernel quantises), 2 = also out-proj / fc2 (their inputs - attention output, MLP
-    hidden - go through tdc_quantize_rows_fp8).  `requested`: False / True (= 1) / 1 / 2."""
+    hidden - go through tdc_quantize_rows_fp8), 3 = as 2 with the MLP hidden written as e4m3 by fc1 itself
+    (tdc_gemm_desc.out_fp8; fp8_level3_ok).  `requested`: False / True (= 1) / 1 / 2 / 3."""
     level = int(requested) if requested else 0
     return level if dim % 128 == 0 else 0
+
+
+def fp8_level3_ok(t):
+    """fc1 can write fc2's e4m3 operand directly when its (padded) output width is fc2's padded K."""
+    Lr = t.layers[0]
+    n_out = Lr.fc1.w.shape[0] // (2 if t.act == "swiglu" else 1)
+    return n_out == Lr.fc2.w.shape[1]
 
 
 def fold_c1(lin):
@@ -196,6 +209,8 @@ def prep_siglip(sd, heads, dtype, dev, patch=14, eps=1e-6, fp8=False):
         t.layers.append(Lr)
         i += 1
     t.mlp = t.layers[0].fc1.n if t.layers else 0
+    if t.fp8 >= 3 and not fp8_level3_ok(t):
+        t.fp8 = 2
     return t
 
 
@@ -249,6 +264,8 @@ def prep_dino(sd, heads, dtype, dev, patch=14, eps=1e-6, fp8=False):
         t.layers.append(Lr)
         i += 1
     t.final_ln = (vec32(sd["layernorm.weight"], dev), vec32(sd["layernorm.bias"], dev))
+    if t.fp8 >= 3 and not fp8_level3_ok(t):
+        t.fp8 = 2
     return t
 
 

@@ -198,6 +198,50 @@ def test_gemm_fp8_operands(ops, dtype, M):
     assert relerr(o32, lin + r32) < 1e-4
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M", [300, 256 * 300 + 77])
+def test_gemm_fp8_output(ops, dtype, M):
+    """tdc_gemm_desc.out_fp8 (fp8 towers level 3): act(A8 W8^T + b) leaves as e4m3 with the analytic per-row scale
+    s_h = (rstd * norm * w2max + bmax)^p / 448; out_stats = (0, s_h * out_wscale).  Checked against the same fp32 product:
+    the scale is exactly the documented bound, no element saturates, and the dequantised rows are at e4m3 precision - as
+    accurate as a tight (row-maximum) scale, because e4m3 is floating point."""
+    from tdc_video_amd import lib as L
+    g = torch.Generator(device="cuda").manual_seed(22)
+    K, N, ws2 = 1152, 1216, 0.37
+    x = torch.randn(M, K, device="cuda", generator=g) * (0.5 + torch.rand(M, 1, device="cuda", generator=g))
+    w = torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)
+    b = torch.randn(N, device="cuda", generator=g)
+    sa = x.abs().amax(1) / 448.0
+    sw = (w.abs().max() / 448.0).item()
+    x8 = (x / sa[:, None]).to(torch.float8_e4m3fn)
+    w8 = (w / sw).to(torch.float8_e4m3fn)
+    norm = x8.float().norm(dim=1) * 1.01
+    stats = torch.stack([norm, sa * sw], 1).contiguous()
+    c1 = torch.zeros(N, device="cuda")
+    w2max, bmax = w8.float().norm(dim=1).max().item(), b.abs().max().item()
+    lin = (x8.float() * sa[:, None]) @ (w8.float() * sw).t() + b
+    bound = sa * sw * norm * w2max + bmax
+    assert bool((lin.abs().amax(1) <= bound).all())
+    for act, want, p in ((L.ACT_NONE, lin, 1), (L.ACT_GELU_TANH, F.gelu(lin, approximate="tanh"), 1),
+                         (L.ACT_GELU_ERF, F.gelu(lin), 1), (L.ACT_SWIGLU, F.silu(lin[:, 0::2]) * lin[:, 1::2], 2)):
+        n_out = want.shape[1]
+        ld = (n_out + 127) // 128 * 128
+        out = torch.full((M, ld), 0x7F, device="cuda", dtype=torch.uint8)       # NaN pattern: untouched bytes show
+        st = torch.empty(M, 2, device="cuda")
+        ops.gemm(x8, w8, b, act=act, out=out, ln_stats=stats, ln_c1=c1, out_dtype=dtype, out_stats=st, out_w2max=w2max,
+                 out_bmax=bmax, out_wscale=ws2)
+        sh = bound ** p / 448.0
+        assert torch.count_nonzero(st[:, 0]) == 0 and ((st[:, 1] / ws2 - sh).abs() / sh).max().item() < 1e-5, act
+        assert bool((out[:, n_out:] == 0x7F).all()), act
+        o = out[:, :n_out].contiguous().view(torch.float8_e4m3fn).float()
+        assert bool(torch.isfinite(o).all()) and o.abs().max().item() <= 448.0, act
+        assert relerr(o * sh[:, None], want) < 0.07, act          # half an e4m3 ulp (2^-4) on the largest element
+        tight = want.abs().amax(1, keepdim=True) / 448.0
+        ref8 = (want / tight).to(torch.float8_e4m3fn).float() * tight
+        rms = lambda t: ((t - want).pow(2).mean() / want.pow(2).mean()).sqrt().item()
+        assert rms(o * sh[:, None]) < 1.1 * rms(ref8) + 1e-3 and rms(ref8) < 0.04, (act, rms(o * sh[:, None]), rms(ref8))
+
+
 def test_quantize_rows_fp8(ops):
     """tdc_quantize_rows_fp8: per-row e4m3 quantisation of a 16-bit matrix (row maximum on 448, zero K padding, stats =
     (0, s_a * wscale)), equal to torch's e4m3 rounding of the scaled row."""
@@ -216,8 +260,8 @@ def test_quantize_rows_fp8(ops):
 @pytest.mark.parametrize("cols", [1152, 1536])
 def test_layernorm_fp8_output(ops, cols):
     """tdc_layernorm's e4m3 output: y8 = LN(x) / s_a with the per-row scale s_a = max|LN(x)| / 448 (so the row maximum lands
-    on the largest e4m3 value), y8_stats = (0, s_a * wscale); dequantised it matches the fp32 LayerNorm to e4m3 precision
-    and equals torch's own e4m3 rounding of the scaled row."""
+    on the largest e4m3 value), y8_stats = (bound of the e4m3 row's 2-norm, s_a * wscale); dequantised it matches the fp32
+    LayerNorm to e4m3 precision and equals torch's own e4m3 rounding of the scaled row."""
     g = torch.Generator(device="cuda").manual_seed(3)
     rows, eps, ws = 777, 1e-6, 0.0123
     x = torch.randn(rows, cols, device="cuda", generator=g) * 3 + 0.5
@@ -228,8 +272,9 @@ def test_layernorm_fp8_output(ops, cols):
     ops.layernorm(x, gm, bt, eps, cols, torch.bfloat16, y8=y8, y8_stats=st, y8_wscale=ws)
     ref = F.layer_norm(x, (cols,), gm, bt, eps)
     sa = ref.abs().amax(1) / 448.0
-    assert torch.count_nonzero(st[:, 0]) == 0
     assert ((st[:, 1] / ws - sa).abs() / sa).max().item() < 1e-5
+    n8 = y8.view(torch.float8_e4m3fn).float().norm(dim=1)      # stats.x bounds the quantised row's norm (out_fp8 consumers)
+    assert bool((st[:, 0] >= n8).all()) and bool((st[:, 0] <= 1.15 * n8).all())
     deq = y8.view(torch.float8_e4m3fn).float() * (st[:, 1] / ws)[:, None]
     assert relerr(deq, ref) < 2 ** -4                    # half an e4m3 ulp at the top of the range
     want = (ref / (st[:, 1] / ws)[:, None]).to(torch.float8_e4m3fn).view(torch.uint8)

@@ -135,17 +135,21 @@ def test_towers_natural_scale(kind, D, heads, mlp, px, fuse, dtype, monkeypatch)
     assert rel(got, ref) < (4e-3 if dtype == torch.float16 else 6e-2)  # bf16: 8 mantissa bits on a raw residual stream
 
 
-@pytest.mark.parametrize("level", [1, 2])
+@pytest.mark.parametrize("level", [1, 2, 3])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("kind,D,heads,mlp,px", [("siglip", 128, 2, 272, 126), ("dino", 256, 4, 344, 126)])
 def test_towers_fp8_operands(kind, D, heads, mlp, px, dtype, level):
     """BASELINE config 5's fp8 MFMA path: the towers' LayerNorms emit e4m3 rows with per-row scales and the qkv / fc1
     GEMMs run on fp8 operands (per-tensor weight scales); HIP vs the fp32 oracle (tolerance: e4m3's 3 mantissa bits on
-    two of the four GEMM inputs of every block), and the C++ composite equals the per-kernel sequence bit for bit."""
+    two of the four GEMM inputs of every block), and the C++ composite equals the per-kernel sequence bit for bit.
+    Level 2: out-proj / fc2 on fp8 operands too; level 3: fc1 writes the e4m3 MLP hidden itself (needs fc1's padded
+    output width == fc2's padded K, else the tower stays at level 2 - covered by the 272-wide SigLIP MLP at level 3)."""
     import tdc_video_amd  # noqa: F401
     from tdc_video_amd import weights as Wt
     from tdc_video_amd.pipeline import VideoEncoder
     g = torch.Generator().manual_seed(12)
+    if level == 3 and kind == "siglip" and dtype == torch.bfloat16:
+        mlp = 384
     grid = px // 14
     sd = _rand_tower_sd(kind, D, heads, mlp, 3, grid if kind == "siglip" else 5, g)
     pixels = torch.rand(5, 3, px, px, generator=g) * 2 - 1
@@ -157,8 +161,9 @@ def test_towers_fp8_operands(kind, D, heads, mlp, px, dtype, level):
     enc._tables = {}
     enc.out_grid = [out_grid, out_grid]
     t = (Wt.prep_siglip if kind == "siglip" else Wt.prep_dino)(sd, heads, dtype, enc.dev, fp8=level)
-    assert t.fp8 == level and t.layers[0].qkv.w.dtype == torch.uint8
-    assert (t.layers[0].fc2.w.dtype == torch.uint8) == (level == 2)     # level 2: out-proj / fc2 on fp8 operands too
+    want_level = 2 if (level == 3 and mlp == 272) else level
+    assert t.fp8 == want_level and t.layers[0].qkv.w.dtype == torch.uint8
+    assert (t.layers[0].fc2.w.dtype == torch.uint8) == (level >= 2)
     enc.towers = {kind: t}
     enc.native_towers = True
     a = enc.tower(kind, pixels.cuda())

@@ -38,10 +38,20 @@ def main():
             t8 = timeit(lambda: ops.gemm(x8, w8, b, act=act, out=out, ln_stats=stats, ln_c1=c1, out_dtype=dt), iters=10)
             os.environ.pop("TDC_GEMM_DEBUG", None)
             res.append((t16, t8))
+        t88 = None
+        if name.endswith("fc1"):    # e4m3 output with analytic row scales (tdc_gemm_desc.out_fp8, fp8 level 3)
+            out8 = torch.empty(M, out.shape[1], device="cuda", dtype=torch.uint8)
+            st2 = torch.empty(M, 2, device="cuda")
+            stn = torch.stack([x8.float().norm(dim=1), sa * sw], 1).contiguous()
+            t88 = timeit(lambda: ops.gemm(x8, w8, b, act=act, out=out8, ln_stats=stn, ln_c1=c1, out_dtype=dt, out_stats=st2,
+                                          out_w2max=float(w8.float().norm(dim=1).max()), out_bmax=float(b.abs().max()),
+                                          out_wscale=1.0), iters=10)
         fl = 2.0 * M * N * K / 1e9
         print("%-11s bf16 %7.3f ms %7.1f TF/s | fp8 %7.3f ms %7.1f TF/s (%+5.1f %%) || no epilogue: bf16 %7.1f TF/s fp8 %7.1f TF/s"
               % (name, res[0][0], fl / res[0][0], res[0][1], fl / res[0][1], 100 * (res[0][0] / res[0][1] - 1),
                  fl / res[1][0], fl / res[1][1]), flush=True)
+        if t88:
+            print("            fp8 operands, e4m3 output: %7.3f ms %7.1f TF/s" % (t88, fl / t88), flush=True)
         del x, w, x16, w16, x8, w8, out
 
 
