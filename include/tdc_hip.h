@@ -97,7 +97,7 @@ typedef struct {
     const float* add; int ldadd; int add_period; int add_mode;
     int rows, cols, dtype;
     tdc_rowmap x_map, y_map; /* row r reads x[x_map(r)] and writes y*[y_map(r)] (identity when seg == 0) */
-    /* fp8 output (may be NULL; y16 / y32 may then be NULL too): y8 [rows, ldy8] OCP e4m3 bytes = y / s_a[r] with the
+    /* fp8 output (may be NULL; when set it is the only output: y16 and y32 must be NULL): y8 [rows, ldy8] OCP e4m3 bytes = y / s_a[r] with the
      * per-row scale s_a[r] = max|y[r]| / 448, pad columns zero; y8_stats[r] = (1.07 ||y[r] / s_a[r]||_2, s_a[r] * y8_wscale) is
      * the ln_stats operand of the fp8-operand tdc_gemm that consumes y8 (y8_wscale = that GEMM's per-tensor weight scale;
      * the first entry - an upper bound of the 2-norm of the QUANTISED row - only matters to tdc_gemm_desc.out_fp8). */

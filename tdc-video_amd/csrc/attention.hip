@@ -45,7 +45,7 @@ template <class T> __device__ __forceinline__ typename VecOf<T>::v4 tr_read(cons
 
 // DK: padded head dim for the QK^T contraction (32/64/96); NDV: number of 16-wide output column tiles; QT: q tiles/wave
 template <class T, int DK, int NDV, int QT, bool VEC, bool BIAS>
-__global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
     typedef typename VecOf<T>::v8 v8;
     typedef typename VecOf<T>::v4 v4;
     constexpr int NCH = DK / 8;                                 // real 16-B chunks per K row
@@ -222,10 +222,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
                     for (int r = 0; r < 4; ++r)
                         if (kv0 + kt * 16 + g * 4 + r >= p.sk) s[t][kt][r] = -INFINITY;
             }
-            float mx = fmaxf(fmaxf(s[t][0][0], s[t][0][1]), fmaxf(s[t][0][2], s[t][0][3]));
+            float mx = fmaxf(s[t][0][0], s[t][0][1]);                              // v_max3_f32 chain: 8 issues / 16 values
+            mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[t][0][2]), s[t][0][3]);
 #pragma unroll
-            for (int kt = 1; kt < 4; ++kt)
-                mx = fmaxf(mx, fmaxf(fmaxf(s[t][kt][0], s[t][kt][1]), fmaxf(s[t][kt][2], s[t][kt][3])));
+            for (int kt = 1; kt < 4; ++kt) {
+                mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[t][kt][0]), s[t][kt][1]);
+                mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[t][kt][2]), s[t][kt][3]);
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float m_new = fmaxf(m_run[t], BIAS ? mx : mx * p.scale_log2);

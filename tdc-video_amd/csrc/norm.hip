@@ -23,7 +23,10 @@ struct LnArgs {
 
 // NV4 = number of 4-column groups per lane: lane l owns columns 4*(l + 64*i) .. +3 (16-byte fp32 / 8-byte 16-bit
 // accesses, consecutive lanes on consecutive addresses).  Requires cols % 4 == 0 and 4-element aligned rows.
-template <class T, int NV4>
+// Q8: the e4m3 output path (y8), a separate instantiation - as a run-time branch it kept the normalised row and the
+// quantisation temporaries live in the 16-bit kernel as well (208 VGPRs instead of 46 at NV4 = 6: a third of the waves,
+// 4 TB/s instead of 6).
+template <class T, int NV4, bool Q8>
 __global__ __launch_bounds__(256) void ln_kernel(LnArgs p) {
     typedef typename VecOf<T>::v4 v4;
     const int lane = threadIdx.x & 63;
@@ -71,16 +74,21 @@ __global__ __launch_bounds__(256) void ln_kernel(LnArgs p) {
     }
     q = wave_sum(q);
     const float rstd = rsqrtf(q / (float)p.cols + p.eps);
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < NV4; ++i) {
         const int c = (lane + i * 64) * 4;
-        if (c < p.pad_cols) {
-            f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (c < p.cols) {
-                const f32x4 gm = *(const f32x4*)(p.gamma + c), bt = *(const f32x4*)(p.beta + c);
+        f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (c < p.cols) {
+            const f32x4 gm = *(const f32x4*)(p.gamma + c), bt = *(const f32x4*)(p.beta + c);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * gm[e] + bt[e];
-            }
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * gm[e] + bt[e];
+        }
+        if (Q8) {           // keep the normalised row (zero beyond cols) for the quantisation pass
+            v[i] = o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(o[e]));
+        } else if (c < p.pad_cols) {
             if (p.y16) {
                 v4 h;
 #pragma unroll
@@ -88,18 +96,9 @@ __global__ __launch_bounds__(256) void ln_kernel(LnArgs p) {
                 *(v4*)((T*)p.y16 + yrow * p.ldy16 + c) = h;
             }
             if (p.y32) *(f32x4*)(p.y32 + yrow * p.ldy32 + c) = o;
-            if (p.y8) v[i] = o;                 // keep the normalised row for the quantisation pass
         }
     }
-    if (p.y8) {
-        float amax = 0.f;
-#pragma unroll
-        for (int i = 0; i < NV4; ++i) {
-            const int c = (lane + i * 64) * 4;
-            if (c < p.cols)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(v[i][e]));
-        }
+    if (Q8) {
         amax = wave_max(amax);
         const float sa = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
         const float inv = 1.0f / sa;
@@ -108,13 +107,10 @@ __global__ __launch_bounds__(256) void ln_kernel(LnArgs p) {
         for (int i = 0; i < NV4; ++i) {
             const int c = (lane + i * 64) * 4;
             if (c < p.pad_cols) {
-                int w = 0;
-                if (c < p.cols) {
-                    const f32x4 q = v[i] * inv;
-                    n2 += (q[0] * q[0] + q[1] * q[1]) + (q[2] * q[2] + q[3] * q[3]);
-                    w = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], w, false);
-                    w = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w, true);
-                }
+                const f32x4 q = v[i] * inv;                 // zero beyond cols
+                n2 += (q[0] * q[0] + q[1] * q[1]) + (q[2] * q[2] + q[3] * q[3]);
+                int w = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], 0, false);
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w, true);
                 *(int*)(p.y8 + yrow * p.ldy8 + c) = w;
             }
         }
@@ -128,13 +124,19 @@ template <class T>
 int launch_ln(const LnArgs& a, hipStream_t st) {
     const int nv = (a.pad_cols + 255) / 256;
     dim3 grid((a.rows + 3) / 4), block(256);
-    if (nv <= 1) hipLaunchKernelGGL((ln_kernel<T, 1>), grid, block, 0, st, a);
-    else if (nv <= 3) hipLaunchKernelGGL((ln_kernel<T, 3>), grid, block, 0, st, a);
-    else if (nv <= 4) hipLaunchKernelGGL((ln_kernel<T, 4>), grid, block, 0, st, a);
-    else if (nv <= 5) hipLaunchKernelGGL((ln_kernel<T, 5>), grid, block, 0, st, a);
-    else if (nv <= 6) hipLaunchKernelGGL((ln_kernel<T, 6>), grid, block, 0, st, a);
-    else if (nv <= 16) hipLaunchKernelGGL((ln_kernel<T, 16>), grid, block, 0, st, a);
+#define LN_LAUNCH(NV)                                                                          \
+    do {                                                                                       \
+        if (a.y8) hipLaunchKernelGGL((ln_kernel<T, NV, true>), grid, block, 0, st, a);         \
+        else hipLaunchKernelGGL((ln_kernel<T, NV, false>), grid, block, 0, st, a);             \
+    } while (0)
+    if (nv <= 1) LN_LAUNCH(1);
+    else if (nv <= 3) LN_LAUNCH(3);
+    else if (nv <= 4) LN_LAUNCH(4);
+    else if (nv <= 5) LN_LAUNCH(5);
+    else if (nv <= 6) LN_LAUNCH(6);
+    else if (nv <= 16) LN_LAUNCH(16);
     else return TDC_E_BADARG;
+#undef LN_LAUNCH
     return (int)hipGetLastError();
 }
 
@@ -211,6 +213,7 @@ __global__ __launch_bounds__(256) void qembed_kernel(QeArgs p) {
 
 extern "C" int tdc_layernorm(const tdc_ln_desc* d, void* stream) {
     if (!d || !d->x || d->rows <= 0 || d->cols <= 0 || (!d->y16 && !d->y32 && !d->y8)) return TDC_E_BADARG;
+    if (d->y8 && (d->y16 || d->y32)) return TDC_E_BADARG;      /* the e4m3 instantiation writes y8 only */
     if (d->y8 && (!d->y8_stats || (d->ldy8 & 3) || ((uintptr_t)d->y8 & 3) || ((uintptr_t)d->y8_stats & 7))) return TDC_E_BADARG;
     LnArgs a;
     a.y8 = (unsigned char*)d->y8; a.ldy8 = d->ldy8; a.st8 = d->y8_stats; a.wscale = d->y8_wscale;
