@@ -45,7 +45,7 @@ template <class T> __device__ __forceinline__ typename VecOf<T>::v4 tr_read(cons
 
 // DK: padded head dim for the QK^T contraction (32/64/96); NDV: number of 16-wide output column tiles; QT: q tiles/wave
 template <class T, int DK, int NDV, int QT, bool VEC, bool BIAS>
-__global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, (QT <= 2 ? 2 : 1)) void attn_kernel(AttnArgs p) {
     typedef typename VecOf<T>::v8 v8;
     typedef typename VecOf<T>::v4 v4;
     constexpr int NCH = DK / 8;                                 // real 16-B chunks per K row
@@ -308,7 +308,17 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs p) {
 
 template <class T, int DK, int NDV, bool VEC, bool BIAS>
 int launch_qt(const AttnArgs& a, int batch, hipStream_t st) {
-    if (a.sq > 64) {
+    // 64 query rows per wave for head dim 64 and long sequences: K / V fragments are read from LDS half as often per MFMA
+    // and each K / V tile is staged for 256 instead of 128 query rows - worth more than the second wave per SIMD it costs
+    // (364 VGPRs): DINOv2 tower shape 603 -> 651 TFLOP/s at a 512-frame batch in isolation (2.78 -> 2.57 ms per launch; inside
+    // the pipeline, behind the qkv GEMM, 2.76 -> 2.71 ms); head dim 72 (404 VGPRs) loses 5 % and stays at 32 rows per wave.
+    // TDC_ATTN_QT4=0 switches it off.
+    static int qt4 = -1;
+    if (qt4 < 0) { const char* e = getenv("TDC_ATTN_QT4"); qt4 = e ? atoi(e) : 1; }
+    if (qt4 && DK == 64 && !BIAS && a.sq > 256) {
+        dim3 grid((a.sq + 255) / 256, a.heads, batch);
+        hipLaunchKernelGGL((attn_kernel<T, DK, NDV, 4, VEC, BIAS>), grid, dim3(256), 0, st, a);
+    } else if (a.sq > 64) {
         dim3 grid((a.sq + 127) / 128, a.heads, batch);
         hipLaunchKernelGGL((attn_kernel<T, DK, NDV, 2, VEC, BIAS>), grid, dim3(256), 0, st, a);
     } else {

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void ln_kernel(LnArgs p) {
     }
     q = wave_sum(q);
     const float rstd = rsqrtf(q / (float)p.cols + p.eps);
-    float amax = 0.f;
+    float amax = 0.f, osq = 0.f;
 #pragma unroll
     for (int i = 0; i < NV4; ++i) {
         const int c = (lane + i * 64) * 4;
@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256) void ln_kernel(LnArgs p) {
             v[i] = o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(o[e]));
+            osq += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
         } else if (c < p.pad_cols) {
             if (p.y16) {
                 v4 h;
@@ -99,24 +100,23 @@ __global__ __launch_bounds__(256) void ln_kernel(LnArgs p) {
         }
     }
     if (Q8) {
-        amax = wave_max(amax);
+        amax = wave_max(amax);          // the two reductions are independent: their cross-lane steps interleave
+        osq = wave_sum(osq);
         const float sa = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
         const float inv = 1.0f / sa;
-        float n2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NV4; ++i) {
             const int c = (lane + i * 64) * 4;
             if (c < p.pad_cols) {
                 const f32x4 q = v[i] * inv;                 // zero beyond cols
-                n2 += (q[0] * q[0] + q[1] * q[1]) + (q[2] * q[2] + q[3] * q[3]);
                 int w = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], 0, false);
                 w = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w, true);
                 *(int*)(p.y8 + yrow * p.ldy8 + c) = w;
             }
         }
-        n2 = wave_sum(n2);
-        // (bound of the 2-norm of the quantised row - e4m3 rounds by at most 2^-4 -, scale): tdc_gemm_desc ln_stats / out_fp8
-        if (lane == 0) *(float2*)(p.st8 + 2 * yrow) = make_float2(1.07f * sqrtf(n2), sa * p.wscale);
+        // (bound of the 2-norm of the quantised row y / s_a - e4m3 rounds by at most 2^-4 -, scale): tdc_gemm_desc ln_stats /
+        // out_fp8
+        if (lane == 0) *(float2*)(p.st8 + 2 * yrow) = make_float2(1.07f * inv * sqrtf(osq), sa * p.wscale);
     }
 }
 
