@@ -51,7 +51,8 @@ extern "C" int tdc_gemm(const tdc_gemm_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (d->out_fp8) {    /* e4m3 output: fp8 operands with their scales, whole 64-column wave tiles, 16-byte rows */
         if (!d->in_fp8 || !d->ln_stats || !d->out_stats || d->out_f32 || d->res || d->c_map.seg != 0 || d->N % 64 != 0 ||
-            (d->ldc & 15) || ((uintptr_t)d->C & 15) || ((uintptr_t)d->out_stats & 7) || !(d->out_w2max > 0.f))
+            (d->ldc & 15) || d->ldc < (d->act == TDC_ACT_SWIGLU ? d->N / 2 : d->N) || ((uintptr_t)d->C & 15) ||
+            ((uintptr_t)d->out_stats & 7) || !(d->out_w2max > 0.f))
             return TDC_E_BADARG;
     }
     if (d->in_fp8) return tdc_gemm_fp8_impl(d, st);

@@ -167,7 +167,7 @@ def test_gemm_layernorm_fusion(ops, dtype, M):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("M", [300, 8192, 80 * 256 - 19])
+@pytest.mark.parametrize("M", [300, 8192, 40 * 256 + 7, 80 * 256 - 19])    # 128x128 (x2), 256x256, persistent
 def test_gemm_fp8_operands(ops, dtype, M):
     """A and W as OCP e4m3 bytes through v_mfma_f32_16x16x128_f8f6f4 (all three GEMM kernels), per-row activation scale x
     per-tensor weight scale applied through the LayerNorm-fold operands.  The reference is the SAME quantised operands
@@ -199,7 +199,7 @@ def test_gemm_fp8_operands(ops, dtype, M):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("M", [300, 256 * 300 + 77])
+@pytest.mark.parametrize("M", [300, 40 * 256 + 7, 256 * 300 + 77])       # 128x128, 256x256 and persistent kernels
 def test_gemm_fp8_output(ops, dtype, M):
     """tdc_gemm_desc.out_fp8 (fp8 towers level 3): act(A8 W8^T + b) leaves as e4m3 with the analytic per-row scale
     s_h = (rstd * norm * w2max + bmax)^p / 448; out_stats = (0, s_h * out_wscale).  Checked against the same fp32 product:
