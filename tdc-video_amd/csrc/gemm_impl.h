@@ -27,6 +27,7 @@ struct GemmArgs {
     int out_fp8; float* out_stats; float out_w2max, out_bmax, out_wscale;
 #ifdef TDC_GEMM_DIAG
     unsigned long long* stamps;   // diagnostics build only (tools/gemm_stamps.cpp): 8 x u64 per workgroup
+    int diag_mode;                // diagnostics build only, TDC_GEMM_DIAGMODE: 1 = no staging (stale LDS), 2 = no MFMAs
 #endif
 };
 
@@ -899,8 +900,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
             dst[j][1] = *(const v8*)(base + (w_off[j] ^ 64));                       \
         }                                                                           \
     }
+#ifdef TDC_GEMM_DIAG
+#define TDC_DIAG_MMA_ON && !(p.diag_mode & 2)
+#else
+#define TDC_DIAG_MMA_ON
+#endif
 #define T2_MMA(MI0, NJ0, fbx)                                                       \
-    if (active) {                                                                   \
+    if (active TDC_DIAG_MMA_ON) {                                                   \
         __builtin_amdgcn_s_setprio(1);                                              \
         if constexpr (FP8) {                                                        \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                           \
@@ -1053,11 +1059,17 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
     const int lds_stage = wave * 2 * 1024;
     // one half-tile (2 x 1 KiB per wave) from the SGPR source `src` (tile base + K offset) + the per-lane offsets
     auto stage_a = [&](int buf, int h, const char* src) {
+#ifdef TDC_GEMM_DIAG
+        if (p.diag_mode & 1) return;
+#endif
         char* dst = smem + buf * T2_BUF + h * T2_HALF + lds_stage;
         __builtin_amdgcn_global_load_lds(GLB_PTR(src + a_so[h][0]), LDS_PTR(dst), 16, 0, 0);
         __builtin_amdgcn_global_load_lds(GLB_PTR(src + a_so[h][1]), LDS_PTR(dst + 1024), 16, 0, 0);
     };
     auto stage_w = [&](int buf, int h, const char* src) {
+#ifdef TDC_GEMM_DIAG
+        if (p.diag_mode & 1) return;
+#endif
         char* dst = smem + buf * T2_BUF + (2 + h) * T2_HALF + lds_stage;
         __builtin_amdgcn_global_load_lds(GLB_PTR(src + w_so[h][0]), LDS_PTR(dst), 16, 0, 0);
         __builtin_amdgcn_global_load_lds(GLB_PTR(src + w_so[h][1]), LDS_PTR(dst + 1024), 16, 0, 0);
@@ -1304,6 +1316,10 @@ int launch(const tdc_gemm_desc* d, hipStream_t st) {
     a.out_fp8 = d->out_fp8; a.out_stats = d->out_stats; a.out_w2max = d->out_w2max; a.out_bmax = d->out_bmax;
     a.out_wscale = d->out_wscale;
     { const char* e = getenv("TDC_GEMM_DEBUG"); a.debug = e ? atoi(e) : 0; }
+    a.diag_mode = 0;
+#ifdef TDC_GEMM_DIAG
+    { const char* e = getenv("TDC_GEMM_DIAGMODE"); a.diag_mode = e ? atoi(e) : 0; }
+#endif
 #ifdef TDC_GEMM_DIAG
     a.stamps = tdc_gemm_diag_stamps;
 #endif
