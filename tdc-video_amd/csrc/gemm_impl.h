@@ -1316,7 +1316,6 @@ int launch(const tdc_gemm_desc* d, hipStream_t st) {
     a.out_fp8 = d->out_fp8; a.out_stats = d->out_stats; a.out_w2max = d->out_w2max; a.out_bmax = d->out_bmax;
     a.out_wscale = d->out_wscale;
     { const char* e = getenv("TDC_GEMM_DEBUG"); a.debug = e ? atoi(e) : 0; }
-    a.diag_mode = 0;
 #ifdef TDC_GEMM_DIAG
     { const char* e = getenv("TDC_GEMM_DIAGMODE"); a.diag_mode = e ? atoi(e) : 0; }
 #endif
