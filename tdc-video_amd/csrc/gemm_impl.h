@@ -666,7 +666,7 @@ __device__ __forceinline__ void epi_staged8_swiglu(const GemmArgs& p, f32x4 (&ac
 
 // fp32 output (+ fp32 residual).  EMIT (LayerNorm fusion, producer side): the updated row also goes out as 16-bit
 // (x16) together with the per-slot (mean, M2) partials - identity row maps, N % 64 == 0.
-template <class T, int RES, int ROWS, bool LB, bool EMIT, bool FOLD = false>
+template <class T, int RES, int ROWS, bool LB, bool EMIT, bool FOLD = false, int RING = 8>
 __device__ __forceinline__ void epi_staged32(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase, int nbase,
                                              int lane, const EpiLane& el) {
     // ROWS = rows staged per pass (256-byte fp32 rows): 64 (16 KiB region) or 16 (4 KiB).  FOLD: the row / column
@@ -678,7 +678,6 @@ __device__ __forceinline__ void epi_staged32(const GemmArgs& p, f32x4 (&acc)[8][
     constexpr int NPASS = 128 / ROWS, QP = ROWS / 4;      // QP read-back instructions (4 rows x 256 B each) per pass
     // The residual loads run as a ring of RING loads ahead of the read-back, independent of the staging passes (they
     // touch no LDS); they come from clamped (always valid) addresses so that no branch - and no vmcnt(0) - separates them.
-    constexpr int RING = 8;
     f32x4 rr[RING];
     auto load_res = [&](int u) {                           // unit u = rows 4u .. 4u+3 of the wave's sub-tile
         const int k = lane & 15;
@@ -774,7 +773,9 @@ __device__ __forceinline__ bool epilogue_staged(const GemmArgs& p, f32x4 (&acc)[
         const int res = p.res ? (p.res_f32 ? 1 : 2) : 0;
         if (p.act != TDC_ACT_NONE || res == 2) return false;
         if (p.x16) epi_staged32<T, 1, R32, SMALL, true>(p, acc, region, mbase, nbase, lane, el);
-        else if (res == 1) epi_staged32<T, 1, R32, SMALL, false>(p, acc, region, mbase, nbase, lane, el);
+        // residual ring: 12 loads ahead in the persistent kernel (same-box A/B against 8: out-projections -2.5 %, fc2 -1 %;
+        // 16 spills), 8 in the one-tile-per-workgroup kernel (12 spills there)
+        else if (res == 1) epi_staged32<T, 1, R32, SMALL, false, false, SMALL ? 12 : 8>(p, acc, region, mbase, nbase, lane, el);
         else epi_staged32<T, 0, R32, SMALL, false>(p, acc, region, mbase, nbase, lane, el);
         return true;
     }
