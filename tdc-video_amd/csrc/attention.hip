@@ -309,9 +309,10 @@ __global__ __launch_bounds__(256, (QT <= 2 ? 2 : 1)) void attn_kernel(AttnArgs p
 template <class T, int DK, int NDV, bool VEC, bool BIAS>
 int launch_qt(const AttnArgs& a, int batch, hipStream_t st) {
     // 64 query rows per wave for head dim 64 and long sequences: K / V fragments are read from LDS half as often per MFMA
-    // and each K / V tile is staged for 256 instead of 128 query rows - worth more than the second wave per SIMD it costs
-    // (364 VGPRs): DINOv2 tower shape 603 -> 651 TFLOP/s at a 512-frame batch in isolation (2.78 -> 2.57 ms per launch; inside
-    // the pipeline, behind the qkv GEMM, 2.76 -> 2.71 ms); head dim 72 (404 VGPRs) loses 5 % and stays at 32 rows per wave.
+    // and each K / V tile is staged for 256 instead of 128 query rows, at 250 VGPRs - still two waves per SIMD (three at 32
+    // rows): DINOv2 tower shape 603 -> 651 TFLOP/s at a 512-frame batch in isolation (2.78 -> 2.57 ms per launch; inside
+    // the pipeline, behind the qkv GEMM, 2.76 -> 2.71 ms); head dim 72 needs 298 VGPRs (one wave per SIMD), loses 5 % and
+    // stays at 32 rows per wave.
     // TDC_ATTN_QT4=0 switches it off.
     static int qt4 = -1;
     if (qt4 < 0) { const char* e = getenv("TDC_ATTN_QT4"); qt4 = e ? atoi(e) : 1; }
