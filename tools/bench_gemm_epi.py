@@ -40,9 +40,13 @@ def main():
             out = torch.empty(M, n_out, device="cuda", dtype=dtype)
             fn = lambda: ops.gemm(a, w, bias=bias, act=act, out=out)
         os.environ.pop("TDC_GEMM_DEBUG", None)
-        ms = timeit(fn, iters=10)
-        os.environ["TDC_GEMM_DEBUG"] = "1"
-        ms0 = timeit(fn, iters=10)
+        timeit(fn, iters=10)          # the first timed batch on fresh buffers runs 10-13 % slow (first touch): discard it
+        ms = ms0 = 1e9
+        for _ in range(2):            # alternate the two forms, keep the better of two batches each
+            os.environ.pop("TDC_GEMM_DEBUG", None)
+            ms = min(ms, timeit(fn, iters=10))
+            os.environ["TDC_GEMM_DEBUG"] = "1"
+            ms0 = min(ms0, timeit(fn, iters=10))
         os.environ.pop("TDC_GEMM_DEBUG", None)
         fl = 2.0 * M * N * K
         layers = 27 if name.startswith("siglip") else 40
