@@ -74,6 +74,10 @@ typedef struct {
     int out_fp8; float* out_stats; float out_w2max, out_bmax, out_wscale;
 } tdc_gemm_desc;
 int tdc_gemm(const tdc_gemm_desc* d, void* stream);
+/* Diagnostics only (tools/, never the product path): 1 = skip the C-tile epilogue (nothing is written), 2 = un-staged
+ * epilogue; 0 (the default) = normal operation.  Prints a warning on stderr when switched on; returns the previous mode.
+ * The library reads no environment variable for this. */
+int tdc_gemm_set_debug(int mode);
 /* per-row e4m3 quantisation of a 16-bit matrix x [rows, ldx] (cols % 8 == 0, cols <= 4608): y8 [rows, ldy8] = x / s_a[r]
  * with s_a[r] = max|x[r]| / 448 (zero bytes up to the next multiple of 128 columns when ldy8 allows), stats[r] =
  * (0, s_a[r] * wscale) - the operands of an fp8-operand tdc_gemm whose input does not come out of a LayerNorm (the
@@ -106,7 +110,7 @@ typedef struct {
 int tdc_layernorm(const tdc_ln_desc* d, void* stream);
 
 /* softmax(Q K^T * scale) V, no mask.  Q element (b, s, h, c) at q + b*q_bs + s*q_rs + h*head_dim + c (same for
- * k, v, o).  head_dim <= 96.  Replaces HF SigLIP/DINOv2 attention (HF:models/siglip/modeling_siglip.py:273-308),
+ * k, v, o).  head_dim <= 80 (TDC_E_BADARG above).  Replaces HF SigLIP/DINOv2 attention (HF:models/siglip/modeling_siglip.py:273-308),
  * BertSelfAttention self and cross (tdc/Qformer.py:169-275). */
 typedef struct {
     const void *q, *k, *v; void* o;

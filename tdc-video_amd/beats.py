@@ -212,21 +212,44 @@ class BeatsEncoder:
             keep.update(fbank=plain, frames=m)
         return x16[:, :C].reshape(B, Lq, C)
 
-    def window_features(self, wav, dist=10):
+    @staticmethod
+    def window_starts(n_samples, dist=10):
+        return list(range(0, int(n_samples / SAMPLE_RATE), dist))
+
+    def window_token_counts(self, n_samples, dist=10):
+        """tokens each 10-second window of an n_samples waveform yields (8 per 16 fbank frames): known without running
+        the encoder, so a rank of the frame-sharded path can lay out the audio plan of the whole video."""
+        out = []
+        for k in self.window_starts(n_samples, dist):
+            n = min(n_samples, int(SAMPLE_RATE * (k + dist))) - SAMPLE_RATE * k
+            out.append((int(L.load().tdc_fbank_frames(n)) // 16) * 8)
+        return out
+
+    def window_features(self, wav, dist=10, only=None):
         """the per-window loop of tdc/cambrian_arch.py:1552-1560 for one video: wav [1, N] -> list of [1, L_w, C].
-        All full 10-second windows go through one batched call, a shorter last window through a second one."""
+        All full 10-second windows go through one batched call, a shorter last window through a second one.
+        only = iterable of window indices: just those windows are encoded and a dict {window: [1, L_w, C]} comes back
+        (every op of the encoder is row- / item-wise, so a window's features do not depend on what shares its batch)."""
         assert wav.dim() == 2 and wav.shape[0] == 1
         N = wav.shape[1]
-        starts = list(range(0, int(N / SAMPLE_RATE), dist))
-        full = [k for k in starts if SAMPLE_RATE * (k + dist) <= N]
+        starts = self.window_starts(N, dist)
+        sel = list(range(len(starts))) if only is None else sorted(set(int(w) for w in only))
+        assert all(0 <= w < len(starts) for w in sel)
+        n = SAMPLE_RATE * dist
+        full = [w for w in sel if SAMPLE_RATE * (starts[w] + dist) <= N]
         out = {}
         if full:
-            n = SAMPLE_RATE * dist
-            batch = wav[0, : len(full) * n].reshape(len(full), n)          # full windows are contiguous from 0
+            if only is None:
+                batch = wav[0, : len(full) * n].reshape(len(full), n)       # full windows are contiguous from 0
+            else:
+                batch = torch.stack([wav[0, SAMPLE_RATE * starts[w]: SAMPLE_RATE * starts[w] + n] for w in full], 0)
             feats = self.extract_features(batch)
-            for i, k in enumerate(full):
-                out[k] = feats[i:i + 1]
-        for k in starts:
-            if k not in out:
-                out[k] = self.extract_features(wav[:, SAMPLE_RATE * k:int(SAMPLE_RATE * (k + dist))])
-        return [out[k] for k in starts]
+            for i, w in enumerate(full):
+                out[w] = feats[i:i + 1]
+        for w in sel:
+            if w not in out:
+                k = starts[w]
+                out[w] = self.extract_features(wav[:, SAMPLE_RATE * k:int(SAMPLE_RATE * (k + dist))])
+        if only is None:
+            return [out[w] for w in sel]
+        return out

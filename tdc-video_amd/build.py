@@ -1,5 +1,5 @@
-"""Build libtdc_hip.so (gfx950) in-tree with hipcc.  Used by __graft_entry__.build() and on first import when the
-library is missing.  hipcc cross-compiles without a GPU."""
+"""Build libtdc_hip.so (gfx950) in-tree with hipcc.  Used by __graft_entry__.build() and by lib.load() when the
+library is missing (under a file lock).  hipcc cross-compiles without a GPU."""
 import os
 import subprocess
 import sys

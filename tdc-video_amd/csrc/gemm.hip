@@ -23,6 +23,17 @@ static int tdc_gemm_fp8_impl(const tdc_gemm_desc*, hipStream_t) { return TDC_E_B
 int tdc_gemm_fp8_impl(const tdc_gemm_desc* d, hipStream_t st);
 #endif
 
+int tdc_gemm_debug_mode = 0;
+
+extern "C" int tdc_gemm_set_debug(int mode) {
+    const int old = tdc_gemm_debug_mode;
+    tdc_gemm_debug_mode = mode;
+    if (mode != 0)
+        fprintf(stderr, "[tdc_hip] WARNING: tdc_gemm diagnostic mode %d is ON - GEMM outputs are NOT valid (timing experiments "
+                        "only); call tdc_gemm_set_debug(0) to restore the product path\n", mode);
+    return old;
+}
+
 extern "C" int tdc_gemm(const tdc_gemm_desc* d, void* stream) {
     if (!d || !d->A || !d->W || !d->C || d->M <= 0 || d->N <= 0 || d->K <= 0) return TDC_E_BADARG;
     const int kmul = d->in_fp8 ? 2 * BK : BK;                  /* one 128-byte K tile: 64 16-bit or 128 fp8 values */

@@ -7,7 +7,18 @@
 #include <stdlib.h>
 #include <type_traits>
 
+// Diagnostic switch of the epilogue (timing experiments only), set through tdc_gemm_set_debug() - never from the
+// environment, so a stale variable cannot silently change what the production library computes.  Defined in gemm.hip.
+extern int tdc_gemm_debug_mode;
+
 namespace {
+
+constexpr int kMaxDev = 64;      // per-device caches below are indexed by hipGetDevice()
+inline int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
+    return dev;
+}
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
@@ -19,7 +30,7 @@ struct GemmArgs {
     int out_f32, res_f32, act;
     RowMap am, cm, rm;
     int tiles_m, tiles_n;
-    int debug;   // TDC_GEMM_DEBUG: 1 = skip the epilogue, 2 = direct (un-staged) epilogue - timing experiments only
+    int debug;   // tdc_gemm_set_debug(): 1 = skip the epilogue, 2 = direct (un-staged) epilogue - timing experiments only
     // LayerNorm fusion (see EpiOps / slot_stats_*): producer side x16 + ln_part, consumer side ln_stats + ln_c1
     void* x16; int ldx16; float* ln_part;
     const float* ln_stats; const float* ln_c1;
@@ -1273,18 +1284,20 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
 // workgroups of the persistent kernel = CUs of the device rounded down to a multiple of 8 (one per CU: 160 KiB of LDS);
 // 0 disables it (TDC_GEMM_PERSIST=0, or a device whose LDS cannot hold 160 KiB per workgroup)
 inline int persistent_grid() {
-    static int grid = -1;
-    if (grid < 0) {
+    static int grid[kMaxDev];
+    static bool known[kMaxDev];
+    const int dev = current_device();
+    if (!known[dev]) {
         const char* e = getenv("TDC_GEMM_PERSIST");
-        int dev = 0;
         hipDeviceProp_t prop;
-        if ((e && atoi(e) == 0) || hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        if ((e && atoi(e) == 0) || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
             prop.sharedMemPerBlock < (size_t)T2P_LDS)
-            grid = 0;
+            grid[dev] = 0;
         else
-            grid = (prop.multiProcessorCount / 8) * 8;
+            grid[dev] = (prop.multiProcessorCount / 8) * 8;
+        known[dev] = true;
     }
-    return grid;
+    return grid[dev];
 }
 
 // kernel choice: the 256^2 8-phase kernel needs enough tiles to fill the 256 CUs; TDC_GEMM_FORCE=128|256 overrides
@@ -1316,7 +1329,7 @@ int launch(const tdc_gemm_desc* d, hipStream_t st) {
     a.x16 = d->x16; a.ldx16 = d->ldx16; a.ln_part = d->ln_part; a.ln_stats = d->ln_stats; a.ln_c1 = d->ln_c1;
     a.out_fp8 = d->out_fp8; a.out_stats = d->out_stats; a.out_w2max = d->out_w2max; a.out_bmax = d->out_bmax;
     a.out_wscale = d->out_wscale;
-    { const char* e = getenv("TDC_GEMM_DEBUG"); a.debug = e ? atoi(e) : 0; }
+    a.debug = tdc_gemm_debug_mode;
 #ifdef TDC_GEMM_DIAG
     { const char* e = getenv("TDC_GEMM_DIAGMODE"); a.diag_mode = e ? atoi(e) : 0; }
 #endif
@@ -1329,7 +1342,10 @@ int launch(const tdc_gemm_desc* d, hipStream_t st) {
     if (use_256(a.M, a.N, a.K)) {
         a.tiles_m = (a.M + 255) / 256;
         a.tiles_n = (a.N + 255) / 256;
-        static bool attr256 = false;
+        // hipFuncSetAttribute is per device: one flag per device and instantiation
+        const int dev = current_device();
+        static bool attr256_dev[kMaxDev];
+        bool& attr256 = attr256_dev[dev];
         if (!attr256) {
             HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm256_kernel<T, FP8>,
                                               hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS));
@@ -1343,7 +1359,8 @@ int launch(const tdc_gemm_desc* d, hipStream_t st) {
                               d->N % (d->act == TDC_ACT_SWIGLU ? 16 : 8) == 0);
         if (G > 0 && a.tiles_m * a.tiles_n > G && d->a_map.seg == 0 && a.K >= 128 && fold_ok &&
             256ll * a.lda * 2 < (1ll << 31) && 256ll * a.ldw * 2 < (1ll << 31)) {
-            static bool attr256p = false;
+            static bool attr256p_dev[kMaxDev];
+            bool& attr256p = attr256p_dev[dev];
             if (!attr256p) {
                 HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm256p_kernel<T, false, FP8>,
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, T2P_LDS));
@@ -1360,7 +1377,8 @@ int launch(const tdc_gemm_desc* d, hipStream_t st) {
     }
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
-    static bool attr_set = false;
+    static bool attr_set_dev[kMaxDev];
+    bool& attr_set = attr_set_dev[current_device()];
     if (!attr_set) {
         HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm_kernel<T, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           4 * TILE_BYTES));

@@ -1,21 +1,29 @@
 """Frame-sharded encoding of ONE long video over the GPUs of a node; one process per GPU,
 torch.distributed (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
 
-Rank r owns the contiguous frames [lo, hi).  Cross-rank data flow per video:
+Rank r owns the contiguous frames [lo, hi) of the frames that survive the a1 cap.  Cross-rank data flow per video:
+  0. a1 (frame budget + uniform sub-sampling) is host integer logic on (T0, text length): every rank computes the same
+     selection (`frame_plan`) and loads / is handed only its own frames.
   1. DINO on the local frames plus a one-frame halo (the next rank's first frame is re-encoded locally: 1/(T/P) extra
      tower work instead of a 1.7 MB send that would serialise the ranks) -> local adjacent similarities;
      all-gather of the T-1 fp32 similarities -> every rank runs the identical stable selection -> identical plan.
-  2. SigLIP + connector on the local frames (no communication).
-  3. Chunks whose key frame lives on another rank: the owner sends its K x Dq query block (K=16: 24 KB) point to point.
+  2. SigLIP + connector on the local frames (no communication).  Audio (a20): a rank runs BEATs on the 10-second windows
+     its own seconds fall into (a window that straddles a rank boundary is encoded by both ranks, like the DINO halo)
+     and builds the audio tokens of its own frames; no exchange.
+  3. Chunks whose key frame lives on another rank: the owner sends its K x Dq query block (K=16: 24 KB) point to point
+     (query_type 'learned': every rank holds the same `query_tokens`, nothing is sent).
   4. Q-Former on the local compressed frames; every rank emits the tokens of its own frames in plan order;
      all-gather (padded to the longest shard; shard lengths are known from the plan) -> identical full stream on every
      rank, tail clipping (a19) already applied through the shared plan.
-The numerical work is delegated to an engine object (pipeline.VideoEncoder on GPUs; a test double in the gloo tests).
+The numerical work is delegated to an engine object (pipeline.VideoEncoder on GPUs; a test double in the gloo tests);
+the transport to a comm object (TorchComm = torch.distributed; the tests also plug in an in-process thread transport to
+rehearse world sizes a one-GPU box cannot host as processes).
 """
+import numpy as np
 import torch
-import torch.distributed as dist
 
 from . import segment as seg
+from .pipeline import sample_indicator
 
 
 def owner_of(frame, ranges):
@@ -26,28 +34,79 @@ def owner_of(frame, ranges):
 
 
 def split_plan(plan, ranges, Nf, K):
-    """Per rank: emission pairs (table,row) in plan order with LOCAL rows; the separator follows its frame."""
-    per = [[] for _ in ranges]
-    comp_local = [dict() for _ in ranges]       # global comp idx -> local comp idx
-    for gi, f in enumerate(plan["comp_frames"]):
-        r = owner_of(f, ranges)
-        comp_local[r][gi] = len(comp_local[r])
-    cur = 0
-    for e in plan["src"]:
-        if e[0] == "f":
-            cur = owner_of(e[1], ranges)
-            per[cur].append((0, (e[1] - ranges[cur][0]) * Nf + e[2]))
-        elif e[0] == "c":
-            cur = owner_of(plan["comp_frames"][e[1]], ranges)
-            per[cur].append((1, comp_local[cur][e[1]] * K + e[2]))
-        else:
-            per[cur].append((2, 0))
+    """Per rank: emission pairs (table, row) in plan order with LOCAL rows (int32 array [n_r, 2]); the separator follows
+    its frame.  Also returns, per rank, the dict global compressed-frame index -> local index."""
+    starts = np.asarray([lo for lo, _ in ranges], dtype=np.int64)
+    comp_frames = np.asarray(plan["comp_frames"] if plan["comp_frames"] else [0], dtype=np.int64)
+    n_comp = len(plan["comp_frames"])
+    comp_owner = np.searchsorted(starts, comp_frames[:max(n_comp, 1)], side="right") - 1
+    comp_local_idx = np.zeros(max(n_comp, 1), dtype=np.int64)
+    comp_local = [dict() for _ in ranges]
+    for r in range(len(ranges)):
+        m = np.nonzero(comp_owner[:n_comp] == r)[0]
+        comp_local_idx[m] = np.arange(len(m))
+        comp_local[r] = {int(g): i for i, g in enumerate(m.tolist())}
+    kind, a, b = plan.kind, plan.a, plan.b
+    n = len(kind)
+    a_c = np.where(kind == 1, a, 0)
+    frame = np.where(kind == 0, a, np.where(kind == 1, comp_frames[a_c], -1))
+    last = np.maximum.accumulate(np.where(kind != 2, np.arange(n), -1)) if n else np.zeros(0, dtype=np.int64)
+    frame_ff = np.where(last >= 0, frame[np.maximum(last, 0)], starts[0]) if n else frame
+    owner = np.searchsorted(starts, frame_ff, side="right") - 1
+    row = np.where(kind == 0, (a - starts[owner]) * Nf + b, np.where(kind == 1, comp_local_idx[a_c] * K + b, 0))
+    both = np.stack([kind, row], 1).astype(np.int32)
+    per = [np.ascontiguousarray(both[owner == r]) for r in range(len(ranges))]
     return per, comp_local
 
 
+class TorchComm:
+    """torch.distributed transport (RCCL on the GPUs of a node; gloo in the CPU tests)."""
+
+    def __init__(self, rank, world, group=None):
+        self.rank, self.world, self.group = rank, world, group
+
+    def all_gather(self, t):
+        import torch.distributed as dist
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t, group=self.group)
+        return out
+
+    def exchange(self, sends, recvs):
+        """sends: [(tensor, dst)], recvs: [(buffer, src)] - posted in this order on every rank, completed before return."""
+        import torch.distributed as dist
+        ops_ = [dist.P2POp(dist.isend, t, dst, self.group) for t, dst in sends] + \
+               [dist.P2POp(dist.irecv, buf, src, self.group) for buf, src in recvs]
+        if ops_:
+            for rq in dist.batch_isend_irecv(ops_):
+                rq.wait()
+
+
 class ShardedVideoEncoder:
-    def __init__(self, engine, rank, world, group=None):
-        self.e, self.rank, self.world, self.group = engine, rank, world, group
+    def __init__(self, engine, rank, world, group=None, comm=None):
+        self.e, self.rank, self.world = engine, rank, world
+        self.comm = comm if comm is not None else TorchComm(rank, world, group)
+
+    # ---- a1 on every rank --------------------------------------------------------------------------------------------
+    def frame_plan(self, T0, budget_text_len, frame_cap=224, video_index=None):
+        """tdc/cambrian_arch.py:899-935 for a T0-frame video: which input frames survive the budget, which of them this rank
+        encodes (`siglip_frames`; `dino_frames` = the same plus the one-frame halo), and the per-second 0/1 vector the audio
+        interleave needs.  Pure host integers: identical on every rank."""
+        cfg = self.e.cfg
+        idx = seg.uniform_indices(T0, min(seg.get_max_num_frames(budget_text_len, cfg), frame_cap))
+        T = len(idx)
+        lo, hi = seg.shard_ranges(T, self.world)[self.rank]
+        halo = 1 if lo < hi < T else 0               # a rank without frames (T < world) has no halo either
+        return dict(idx=idx, T=T, lo=lo, hi=hi, siglip_frames=idx[lo:hi], dino_frames=idx[lo:hi + halo],
+                    sample_indices=sample_indicator(T0, idx, video_index))
+
+    def _tokens_per_frame(self, image_size, audio):
+        """rows per frame in the Q-Former KV / static emission (cur_h * (cur_w + 1), + 50 with audio) without running the
+        connector - only a rank that owns no frame needs it (to lay out the shared plan)."""
+        side = getattr(self.e, "side", None)
+        if side is None:
+            return self.e.N + (0 if audio is None else 2)          # CPU test double
+        r0, r1, c0, c1 = seg.unpad_bounds(side, side, image_size)
+        return (r1 - r0) * (c1 - c0 + 1) + (50 if audio is not None else 0)
 
     def _all_gather_var(self, t, counts):
         """all-gather of 1-D/2-D tensors with per-rank leading sizes `counts` (known to every rank)."""
@@ -55,12 +114,15 @@ class ShardedVideoEncoder:
         pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         if t.shape[0]:
             pad[: t.shape[0]] = t
-        out = [torch.empty_like(pad) for _ in range(self.world)]
-        dist.all_gather(out, pad, group=self.group)
+        out = self.comm.all_gather(pad)
         return torch.cat([o[:c] for o, c in zip(out, counts)], 0)
 
-    def encode_video(self, px_siglip_local, px_dino_local_halo, T, image_size, n_text_tokens, prompt_ids):
-        """px_siglip_local: frames [lo,hi); px_dino_local_halo: frames [lo, hi + 1) (no halo on the last rank)."""
+    def encode_video(self, px_siglip_local, px_dino_local_halo, T, image_size, n_text_tokens, prompt_ids, audio=None,
+                     sample_indices=None):
+        """px_siglip_local: frames [lo,hi) of the T frames that survive a1 (frame_plan); px_dino_local_halo: frames
+        [lo, hi + 1) (no halo on the last rank).  audio: as in the serial path - a full [T, 50, 768] token tensor, or a dict
+        with "audio_tokens" / "beats_windows" (all windows) / "audio_wav" (raw 16 kHz waveform: BEATs runs here, on this
+        rank's windows only); sample_indices: frame_plan's per-second vector (all ones when a1 did not cap)."""
         e, rank, world = self.e, self.rank, self.world
         ranges = seg.shard_ranges(T, world)
         lo, hi = ranges[rank]
@@ -68,10 +130,23 @@ class ShardedVideoEncoder:
         cfg = e.cfg
         # 1. DINO (+halo) -> similarities -> identical segmentation everywhere
         n_d = px_dino_local_halo.shape[0]
-        assert n_d == Tl + (1 if rank < world - 1 else 0)
+        assert n_d == Tl + (1 if lo < hi < T else 0) and px_siglip_local.shape[0] == Tl
+        if Tl == 0:
+            # more ranks than frames (T < world <= 8 < max_num_segments + 1: the pass-through case, no similarities, no
+            # Q-Former): this rank only takes part in the final all-gather
+            assert T <= cfg.get("max_num_segments", 24) + 1
+            Nf = self._tokens_per_frame(image_size, audio)
+            plan = seg.emit_plan(T, Nf, e.K, list(range(T)), cfg["tokenizer_model_max_length"] -
+                                 cfg.get("inference_max_length", 16) - n_text_tokens, cfg.get("add_static", True))
+            pairs, _ = split_plan(plan, ranges, Nf, e.K)
+            if cfg.get("query_type", "Avg_pool") != "learned":
+                self.comm.exchange([], [])
+            local = torch.zeros(0, e.H, dtype=e.dtype, device=px_siglip_local.device)
+            return self._all_gather_var(local, [len(p) for p in pairs])
         dino_all = e.tower("dino", px_dino_local_halo)
         P = dino_all.shape[0] // n_d
         mns = cfg.get("max_num_segments", 24)
+        sig = None
         if T <= mns + 1:
             seg_idx = list(range(T))
         else:
@@ -79,57 +154,65 @@ class ShardedVideoEncoder:
                 sims_local = e.sims_tensor(dino_all, n_d)
             else:
                 sims_local = torch.zeros(0, dtype=torch.float32, device=dino_all.device)
+            # the local SigLIP tower is enqueued before the exchange: the device works while the similarities travel
+            sig = e.tower("siglip", px_siglip_local)
             counts = [(h - l) - (0 if r < world - 1 else 1) for r, (l, h) in enumerate(ranges)]
             sims = self._all_gather_var(sims_local, counts).tolist()
             assert len(sims) == T - 1
             seg_idx = seg.select_segments(sims, mns)
         dino = dino_all[: Tl * P]
-        # 2. local towers + connector
-        sig = e.tower("siglip", px_siglip_local)
+        # 2. local towers + connector (+ audio rows of the local frames)
+        if sig is None:
+            sig = e.tower("siglip", px_siglip_local)
         X, sizes = e.connector(sig, dino, Tl, [tuple(image_size)] * Tl)
         N = X.shape[0] // Tl
         K = e.K
+        if sample_indices is None:
+            sample_indices = [1] * T
+        Xf, Nf = e.with_audio(X, Tl, N, e.local_audio(audio, sample_indices, T, lo, hi))
         # 3. shared plan, query hand-off
         max_visual_len = cfg["tokenizer_model_max_length"] - cfg.get("inference_max_length", 16) - n_text_tokens
-        if cfg.get("query_type", "Avg_pool") != "Avg_pool":
-            raise NotImplementedError("frame sharding implements the default query_type='Avg_pool' hand-off only")
-        plan = seg.emit_plan(T, N, K, seg_idx, max_visual_len, cfg.get("add_static", True))
-        pairs, comp_local = split_plan(plan, ranges, N, K)
+        plan = seg.emit_plan(T, Nf, K, seg_idx, max_visual_len, cfg.get("add_static", True))
+        pairs, comp_local = split_plan(plan, ranges, Nf, K)
         keys = plan["key_frames"]
         my_comp = [gi for gi, f in enumerate(plan["comp_frames"]) if lo <= f < hi]
-        need = sorted(set(plan["comp_chunk"][gi] for gi in my_comp))
-        owned = [c for c, s in enumerate(keys) if lo <= s < hi]
-        q_owned = e.make_queries(X, N, N, [keys[c] - lo for c in owned]) if owned else None
-        users = {}                               # chunk -> ranks that hold compressed frames of it
-        for gi, f in enumerate(plan["comp_frames"]):
-            users.setdefault(plan["comp_chunk"][gi], set()).add(owner_of(f, ranges))
-        p2p, recv_buf = [], {}
-        for ci, c in enumerate(owned):                       # ascending chunk id on both sides: pairwise order matches
-            for r in sorted(users.get(c, ())):
-                if r != rank:
-                    p2p.append(dist.P2POp(dist.isend, q_owned[ci * K:(ci + 1) * K].contiguous(), r, self.group))
-        for c in need:
-            if not (lo <= keys[c] < hi):
-                buf = torch.empty((K, e.query_width()), dtype=e.dtype, device=X.device)
-                recv_buf[c] = buf
-                p2p.append(dist.P2POp(dist.irecv, buf, owner_of(keys[c], ranges), self.group))
-        if p2p:
-            for rq in dist.batch_isend_irecv(p2p):
-                rq.wait()
+        pid = prompt_ids if cfg.get("text_input", True) else None
         comp = None
-        if my_comp:
-            blocks = []
+        if cfg.get("query_type", "Avg_pool") == "learned":          # cambrian_arch.py:1639-1640: one shared query block
+            if my_comp:
+                comp = e.compress_frames(Xf, Nf, [plan["comp_frames"][gi] - lo for gi in my_comp], e.learned_queries(),
+                                         [0] * len(my_comp), pid)
+        else:
+            need = sorted(set(plan["comp_chunk"][gi] for gi in my_comp))
+            owned = [c for c, s in enumerate(keys) if lo <= s < hi]
+            q_owned = e.make_queries(Xf, N, Nf, [keys[c] - lo for c in owned]) if owned else None
+            users = {}                               # chunk -> ranks that hold compressed frames of it
+            for gi, f in enumerate(plan["comp_frames"]):
+                users.setdefault(plan["comp_chunk"][gi], set()).add(owner_of(f, ranges))
+            sends, recvs, recv_buf = [], [], {}
+            for ci, c in enumerate(owned):                   # ascending chunk id on both sides: pairwise order matches
+                for r in sorted(users.get(c, ())):
+                    if r != rank:
+                        sends.append((q_owned[ci * K:(ci + 1) * K].contiguous(), r))
             for c in need:
-                if c in recv_buf:
-                    blocks.append(recv_buf[c])
-                else:
-                    ci = owned.index(c)
-                    blocks.append(q_owned[ci * K:(ci + 1) * K])
-            qtable = torch.cat(blocks, 0)
-            qsrc = [need.index(plan["comp_chunk"][gi]) for gi in my_comp]
-            comp = e.compress_frames(X, N, [plan["comp_frames"][gi] - lo for gi in my_comp], qtable, qsrc, prompt_ids)
+                if not (lo <= keys[c] < hi):
+                    buf = torch.empty((K, e.query_width()), dtype=e.dtype, device=X.device)
+                    recv_buf[c] = buf
+                    recvs.append((buf, owner_of(keys[c], ranges)))
+            self.comm.exchange(sends, recvs)
+            if my_comp:
+                blocks = []
+                for c in need:
+                    if c in recv_buf:
+                        blocks.append(recv_buf[c])
+                    else:
+                        ci = owned.index(c)
+                        blocks.append(q_owned[ci * K:(ci + 1) * K])
+                qtable = torch.cat(blocks, 0)
+                qsrc = [need.index(plan["comp_chunk"][gi]) for gi in my_comp]
+                comp = e.compress_frames(Xf, Nf, [plan["comp_frames"][gi] - lo for gi in my_comp], qtable, qsrc, pid)
         # 4. local emission + all-gather
         mine = pairs[rank]
-        local = e.emit(X, comp, mine) if mine else torch.zeros(0, e.H, dtype=e.dtype, device=X.device)
+        local = e.emit(Xf, comp, mine) if len(mine) else torch.zeros(0, e.H, dtype=e.dtype, device=X.device)
         counts = [len(p) for p in pairs]
         return self._all_gather_var(local, counts)

@@ -122,6 +122,7 @@ class QformerModel(C.Structure):
 # name -> (restype, argtypes); every symbol include/tdc_hip.h declares
 SIGNATURES = {
     "tdc_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
+    "tdc_gemm_set_debug": (C.c_int, [C.c_int]),
     "tdc_ln_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "tdc_quantize_rows_fp8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                         C.c_float, C.c_void_p]),
@@ -174,8 +175,27 @@ class TdcHipError(RuntimeError):
     pass
 
 
+def _build_once():
+    """Fresh checkout: compile the library (hipcc, ~2.5 min) exactly once even when several ranks import at the same time
+    (file lock; the losers find the finished .so).  Never rebuilds an existing library - staleness is build.py's business."""
+    import fcntl
+    import importlib.util
+    lock = open(os.path.join(HERE, ".build.lock"), "w")
+    try:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not os.path.exists(LIB_PATH):
+            spec = importlib.util.spec_from_file_location("tdc_build", os.path.join(HERE, "build.py"))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            mod.build()
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
 def load():
-    """Load libtdc_hip.so (built in-tree by build.py).  Raises if missing: there is no CPU fallback."""
+    """Load libtdc_hip.so (built in-tree by build.py; compiled here, once, when it is missing).  Raises if it cannot be
+    loaded: there is no CPU fallback."""
     global _lib
     if _lib is not None:
         return _lib
@@ -183,8 +203,10 @@ def load():
     # pull /opt/rocm's copy in and the two runtimes do not share devices/streams (hipErrorNoDevice at first launch).
     import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
-        raise TdcHipError("libtdc_hip.so not found at %s: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                          "(the product path has no CPU fallback)" % LIB_PATH)
+        _build_once()
+    if not os.path.exists(LIB_PATH):
+        raise TdcHipError("libtdc_hip.so not found at %s and could not be built: run `python -c 'import __graft_entry__ "
+                          "as g; g.build()'` (the product path has no CPU fallback)" % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing

@@ -490,9 +490,12 @@ class CambrianMetaForCausalLM(ABC):
                         and emb_w.device == eng.dev and emb_w.dtype == eng.dtype and len(pos_img) == 1):
                     splice = {"table": emb_w, "before": cur_ids[:pos_img[0]].tolist(),
                               "after": cur_ids[pos_img[0] + 1:].tolist()}
+                # video_indices[i]: 0/1 per second of audio, 1 where a frame was decoded (cambrian_arch.py:916-926); [None]
+                # (what generate() passes) / None: input frame t is second t
+                vindex = video_indices[i] if video_indices is not None and i < len(video_indices) else None
                 vis = eng.encode_video(vid_s.to(eng.dev), vid_d.to(eng.dev), tuple(image_sizes[i]),
                                        budget_text_len=self._budget_text_len(input_ids[i]), n_text_tokens=n_text,
-                                       prompt_ids=prompt_ids, audio=audio, keep=keep, splice=splice)
+                                       prompt_ids=prompt_ids, audio=audio, keep=keep, splice=splice, video_index=vindex)
                 spliced.append(splice is not None)
             else:
                 # single images: every image is a static frame, no segmentation / Q-Former (cambrian_arch.py:980-983)

@@ -338,8 +338,22 @@ def adaptive_pool_tokens(x, N, K, B, src_row=None, frame_rows=None):
     return y
 
 
-def gather_rows(tables, src, n, cols, out=None):
-    """tables: list of <= 4 2-D 16-bit tensors; src int32 [n, 2] (table, row)."""
+def check_pairs_host(pairs, table_rows):
+    """host-side range check of a (table, row) gather map (numpy int array [n, 2]) against the tables' row counts - the
+    kernel trusts its indices, and a faulting kernel can take the whole GPU node down."""
+    import numpy as np
+    p = np.asarray(pairs).reshape(-1, 2)
+    if p.shape[0] == 0:
+        return
+    assert p[:, 0].min() >= 0 and p[:, 0].max() < len(table_rows), "gather table out of range"
+    assert p[:, 1].min() >= 0, "negative gather row"
+    lim = np.asarray(table_rows, dtype=np.int64)[p[:, 0]]
+    assert (p[:, 1] < lim).all(), "gather row out of range"
+
+
+def gather_rows(tables, src, n, cols, out=None, validated=False):
+    """tables: list of <= 4 2-D 16-bit tensors; src int32 [n, 2] (table, row) on the device.  validated=True: the caller
+    has range-checked the map on the host (check_pairs_host) - skips the device-side check and its synchronisations."""
     gt = L.GatherTables()
     dtype = tables[0].dtype
     rows_ok = []
@@ -351,12 +365,13 @@ def gather_rows(tables, src, n, cols, out=None):
         gt.ld[i] = t.stride(0)
         rows_ok.append(t.shape[0])
     assert src.dtype == torch.int32 and src.is_contiguous() and src.numel() >= 2 * n
-    s = src.view(-1, 2)[:n]
-    assert int(s[:, 0].max()) < len(tables) and int(s[:, 0].min()) >= 0
-    for i, r in enumerate(rows_ok):
-        sel = s[:, 1][s[:, 0] == i]
-        if sel.numel():
-            assert int(sel.max()) < r and int(sel.min()) >= 0, "gather row out of range"
+    if not validated:
+        s = src.view(-1, 2)[:n]
+        assert int(s[:, 0].max()) < len(tables) and int(s[:, 0].min()) >= 0
+        for i, r in enumerate(rows_ok):
+            sel = s[:, 1][s[:, 0] == i]
+            if sel.numel():
+                assert int(sel.max()) < r and int(sel.min()) >= 0, "gather row out of range"
     if out is None:
         out = torch.empty(n, cols, device=src.device, dtype=dtype)
     assert out.shape[0] >= n and out.shape[1] >= cols and out.stride(1) == 1

@@ -246,16 +246,7 @@ class VideoEncoder:
         P = aux[0].shape[0] // T
         n = int(round(P ** 0.5))
         r = n // side
-        # masks (host geometry, identical for frames that share an image size)
-        cache = {}
-        rows = []
-        for t in range(T):
-            key = tuple(image_sizes[t])
-            if key not in cache:
-                m0 = seg.window_mask_bytes(side, r, key)
-                cache[key] = [a + b for a, b in zip(m0, m0)]  # both towers share the geometry (same grid)
-            rows.extend(cache[key])
-        mask = torch.tensor(rows, dtype=torch.uint8, device=dev).contiguous()
+        mask, _ = self._window_mask(T, P, image_sizes)      # host geometry, cached per (T, image size)
         ctx = ops.token_mean(aux[0], T, P)                                    # [T, Cp]
         q16 = torch.zeros(T * nq, Cp, device=dev, dtype=dt)
         q16[:, :C] = c.vision_query.to(dt).to(dev)[None, :]
@@ -282,21 +273,33 @@ class VideoEncoder:
         return ops.gemm(h, self.c.mm2.w, self.c.mm2.b)
 
     def unpad_newline(self, feat, T, image_sizes):
-        """feat [T*nq, Hp] -> X [T*N, Hp] with the newline column appended (all frames of a video share image_size)."""
+        """feat [T*nq, Hp] -> X [T*N, Hp] with the newline column appended (all frames of a video share image_size).
+        The gather map depends only on (T, image sizes): built once on the host, kept on the device."""
         side = self.side
-        src, sizes = [], []
-        cache = {}
-        for t in range(T):
-            key = tuple(image_sizes[t])
-            if key not in cache:
-                cache[key] = seg.unpad_newline_map(side, key, 0)
-            m, sz = cache[key]
-            src.extend((k, r + (t * side * side if k == 0 else 0)) for (k, r) in m)
-            sizes.append(sz)
-        idx = torch.tensor(src, dtype=torch.int32, device=self.dev).contiguous()
+        key = ("unpad", T, tuple(image_sizes[0]) if len(set(map(tuple, image_sizes))) == 1 else tuple(map(tuple, image_sizes)))
+        hit = self._tables.get(key)
+        if hit is None:
+            import numpy as np
+            cache, blocks, sizes = {}, [], []
+            for t in range(T):
+                k = tuple(image_sizes[t])
+                if k not in cache:
+                    m, sz = seg.unpad_newline_map(side, k, 0)
+                    cache[k] = (np.asarray(m, dtype=np.int32).reshape(-1, 2), sz)
+                m, sz = cache[k]
+                blk = m.copy()
+                blk[:, 1] += np.where(m[:, 0] == 0, t * side * side, 0).astype(np.int32)
+                blocks.append(blk)
+                sizes.append(sz)
+            idx_np = np.concatenate(blocks, 0)
+            ops.check_pairs_host(idx_np, [T * side * side, 1])
+            idx = torch.from_numpy(idx_np).to(self.dev).contiguous()
+            hit = self._tables[key] = (idx, sizes)
+        idx, sizes = hit
         Hp = feat.shape[1]
-        X = ops.gather_rows([feat, self.c.image_newline], idx, len(src), Hp)
-        return X, sizes
+        assert feat.shape[0] >= T * side * side
+        X = ops.gather_rows([feat, self.c.image_newline], idx, idx.shape[0], Hp, validated=True)
+        return X, list(sizes)
 
     # ---- native composite (csrc/api.cpp: tdc_connector_fwd): a6-a9 in one C call ------------------------------------------
     def _connector_struct(self):
@@ -334,14 +337,20 @@ class VideoEncoder:
     def _window_mask(self, T, P, image_sizes):
         side = self.side
         r = int(round(P ** 0.5)) // side
-        cache, rows = {}, []
-        for t in range(T):
-            key = tuple(image_sizes[t])
-            if key not in cache:
-                m0 = seg.window_mask_bytes(side, r, key)
-                cache[key] = [a + b for a, b in zip(m0, m0)]  # both towers share the geometry (same grid)
-            rows.extend(cache[key])
-        return torch.tensor(rows, dtype=torch.uint8, device=self.dev).contiguous(), r
+        key = ("mask", T, P, tuple(image_sizes[0]) if len(set(map(tuple, image_sizes))) == 1 else tuple(map(tuple, image_sizes)))
+        hit = self._tables.get(key)
+        if hit is None:
+            import numpy as np
+            cache, rows = {}, []
+            for t in range(T):
+                k = tuple(image_sizes[t])
+                if k not in cache:
+                    m0 = seg.window_mask_bytes(side, r, k)
+                    # both towers share the geometry (same grid)
+                    cache[k] = np.asarray([a + b for a, b in zip(m0, m0)], dtype=np.uint8)
+                rows.append(cache[k])
+            hit = self._tables[key] = torch.from_numpy(np.concatenate(rows, 0)).to(self.dev).contiguous()
+        return hit, r
 
     def _connector_native(self, sig_feat, dino_feat, T, image_sizes):
         import ctypes as C
@@ -384,9 +393,7 @@ class VideoEncoder:
         K = self.K
         heads = self.qheads
         hd = Dq // heads
-        ids = None
-        if prompt_ids is not None and len(prompt_ids) > 0:
-            ids = torch.as_tensor(prompt_ids, dtype=torch.int32, device=self.dev).contiguous()
+        ids = self._prompt_tensor(prompt_ids)
         Lt = 0 if ids is None else ids.numel()
         S = K + Lt
         h32, h16 = ops.qformer_embed(query, qsrc, qf.word, qf.pos, ids, qf.emb_ln[0], qf.emb_ln[1], 1e-12, F, K, Dq, dt)
@@ -427,36 +434,78 @@ class VideoEncoder:
                               y_map=tmap)
         return h16, S
 
-    def audio_tokens(self, beats_windows, sample_indices, T):
-        """a20 (tdc/cambrian_arch.py:1552-1598): BEATs window features [1, n_w, 768] -> audio tokens [T, 50, 768] 16-bit
-        (pooling of short / dropped seconds with tdc_adaptive_pool_tokens, zero padded tail)."""
+    def audio_tokens(self, beats_windows, sample_indices, T, lo=0, hi=None, window_sizes=None):
+        """a20 (tdc/cambrian_arch.py:1552-1598): BEATs window features -> audio tokens of frames [lo, hi) of the T frames,
+        [hi - lo, 50, 768] 16-bit (pooling of short / dropped seconds with tdc_adaptive_pool_tokens, zero padded tail).
+        beats_windows: list of [1, n_w, 768] for ALL windows, or a dict {window: features} holding at least the windows the
+        frames [lo, hi) draw from, together with window_sizes = token count of every window."""
         dt, dev = self.dtype, self.dev
-        wins = []
-        for w in beats_windows:
-            w2 = w.reshape(-1, w.shape[-1]).to(dev)
-            buf = torch.zeros(w2.shape[0], pad64(w2.shape[1]), device=dev, dtype=dt)
-            buf[:, : w2.shape[1]] = w2.to(dt)
-            wins.append(buf)
-        Da = beats_windows[0].shape[-1]
-        plan = seg.audio_plan([w.shape[0] for w in wins], [int(v) for v in sample_indices])
-        out = torch.zeros(T, 50, Da, device=dev, dtype=dt)
+        hi = T if hi is None else hi
+        if isinstance(beats_windows, dict):
+            assert window_sizes is not None
+            src = beats_windows
+        else:
+            src = dict(enumerate(beats_windows))
+            window_sizes = [int(w.reshape(-1, w.shape[-1]).shape[0]) for w in beats_windows]
+        Da = next(iter(src.values())).shape[-1]
+        plan = seg.audio_plan(list(window_sizes), [int(v) for v in sample_indices])
+        wins = {}
+
+        def win(w):
+            if w not in wins:
+                w2 = src[w].reshape(-1, Da).to(dev)
+                assert w2.shape[0] == window_sizes[w]
+                buf = torch.zeros(w2.shape[0], pad64(Da), device=dev, dtype=dt)
+                buf[:, :Da] = w2.to(dt)
+                wins[w] = buf
+            return wins[w]
+        out = torch.zeros(hi - lo, 50, Da, device=dev, dtype=dt)
 
         def pooled50(x):
             return x if x.shape[0] == 50 else ops.adaptive_pool_tokens(x.contiguous(), x.shape[0], 50, 1)
-        for i, (parts, direct) in enumerate(plan[:T]):
-            toks = [pooled50(wins[w][s:e]) for (w, s, e) in parts]
+        for i in range(lo, min(hi, T, len(plan))):
+            parts, direct = plan[i]
+            toks = [pooled50(win(w)[s:e]) for (w, s, e) in parts]
             x = toks[0] if len(toks) == 1 else pooled50(torch.cat(toks, 0))
-            out[i] = x[:, :Da]
+            out[i - lo] = x[:, :Da]
         return out
 
-    def beats_windows(self, wav, mask=None):
+    def beats_windows(self, wav, mask=None, only=None):
         """tdc/cambrian_arch.py:1552-1560: BEATs features of the consecutive 10-s windows of wav [1, n] (16 kHz).
-        `self.beats` is a beats.BeatsEncoder (set by the owner of the weights, e.g. model.initialize_audio)."""
+        `self.beats` is a beats.BeatsEncoder (set by the owner of the weights, e.g. model.initialize_audio).
+        only = set of window indices -> dict {window: features} of just those windows."""
         if getattr(self, "beats", None) is None:
             raise RuntimeError("raw audio given but no BEATs encoder is attached (VideoEncoder.beats)")
         if mask is not None and bool(torch.as_tensor(mask).bool().any()):
             raise NotImplementedError("padded audio (audio_wav_mask with True entries)")
-        return self.beats.window_features(wav)
+        return self.beats.window_features(wav, only=only)
+
+    def local_audio(self, audio, sample_indices, T, lo=0, hi=None):
+        """a20 for the frames [lo, hi) of the T kept frames: the caller's `audio` (None, a [T, 50, 768] token tensor, or
+        the dict forms of prepare_inputs_labels_for_multimodal) -> [hi - lo, 50, 768] audio tokens (None without audio).
+        With a raw waveform only the BEATs windows those frames draw from are encoded (frame sharding: dist.py)."""
+        hi = T if hi is None else hi
+        if audio is None:
+            return None
+        if not isinstance(audio, dict):
+            return audio[lo:hi]
+        if audio.get("audio_tokens") is not None:
+            return audio["audio_tokens"][lo:hi]
+        wins = audio.get("beats_windows")
+        if wins is not None:
+            return self.audio_tokens(wins, sample_indices, T, lo, hi)
+        wav = audio["audio_wav"]                               # raw 16 kHz waveform: BEATs on the device (8(f)-1)
+        if getattr(self, "beats", None) is None:
+            raise RuntimeError("raw audio given but no BEATs encoder is attached (VideoEncoder.beats)")
+        sizes = self.beats.window_token_counts(wav.shape[1])
+        plan = seg.audio_plan(sizes, [int(v) for v in sample_indices])
+        need = sorted({w for i in range(lo, min(hi, T, len(plan))) for (w, _, _) in plan[i][0]})
+        if lo == 0 and hi >= T:
+            need = None                                        # the whole video: every window, one batched call
+        feats = self.beats_windows(wav, audio.get("audio_wav_mask"), only=need)
+        if need is None:
+            return self.audio_tokens(feats, sample_indices, T, lo, hi)
+        return self.audio_tokens(feats, sample_indices, T, lo, hi, window_sizes=sizes)
 
     def with_audio(self, X, T, N, audio):
         """a20: frames become [visual N | audio_proj(audio) Na] rows (tdc/cambrian_arch.py:1611-1614)."""
@@ -521,16 +570,25 @@ class VideoEncoder:
         self._qf_struct = (m, layers)
         return self._qf_struct
 
+    def _prompt_tensor(self, prompt_ids):
+        """BERT prompt ids as a device int32 tensor, validated on the host (an out-of-range id would fault in the kernel)."""
+        if prompt_ids is None or len(prompt_ids) == 0:
+            return None
+        key = ("ids", tuple(int(i) for i in prompt_ids))
+        hit = self._tables.get(key)
+        if hit is None:
+            qf = self.c.qformer
+            assert max(key[1]) < qf.word.shape[0] and min(key[1]) >= 0 and len(key[1]) <= qf.pos.shape[0]
+            hit = self._tables[key] = torch.tensor(key[1], dtype=torch.int32, device=self.dev)
+        return hit
+
     def _compress_native(self, enc, F, Nf, qtable, qs, prompt_ids):
         import ctypes as C
         m = self._qformer_struct()[0]
-        ids = None
-        if prompt_ids is not None and len(prompt_ids) > 0:
-            ids = torch.as_tensor(prompt_ids, dtype=torch.int32, device=self.dev).contiguous()
-            assert int(ids.max()) < self.c.qformer.word.shape[0] and len(ids) <= self.c.qformer.pos.shape[0]
+        ids = self._prompt_tensor(prompt_ids)
         Lt = 0 if ids is None else ids.numel()
         K = self.K
-        assert qs.dtype == torch.int32 and qs.numel() >= F and (int(qs.max()) + 1) * K <= qtable.shape[0]
+        assert qs.dtype == torch.int32 and qs.numel() >= F        # value range checked on the host list (compress_frames)
         assert enc.shape[0] >= F * Nf and enc.shape[1] >= m.cross_kv.k and qtable.shape[1] >= pad64(m.dim)
         lib = L.load()
         need = lib.tdc_qformer_workspace_bytes(C.byref(m), F, K, Lt, Nf)
@@ -549,8 +607,12 @@ class VideoEncoder:
         K, H = self.K, c.H
         F = len(frame_rows)
         Hp = Xf.shape[1]
-        enc_idx = torch.tensor([(0, f * Nf + i) for f in frame_rows for i in range(Nf)], dtype=torch.int32, device=dev)
-        enc = ops.gather_rows([Xf], enc_idx, F * Nf, Hp)
+        assert F == len(qsrc) and (max(qsrc) + 1) * K <= qtable.shape[0] and min(qsrc) >= 0
+        assert min(frame_rows) >= 0 and (max(frame_rows) + 1) * Nf <= Xf.shape[0]
+        fr = torch.tensor(frame_rows, dtype=torch.int32, device=dev)
+        enc_idx = torch.zeros(F * Nf, 2, dtype=torch.int32, device=dev)
+        enc_idx[:, 1] = (fr[:, None] * Nf + torch.arange(Nf, dtype=torch.int32, device=dev)[None, :]).reshape(-1)
+        enc = ops.gather_rows([Xf], enc_idx, F * Nf, Hp, validated=True)      # frame_rows range-checked above
         qs = torch.tensor(qsrc, dtype=torch.int32, device=dev)
         if getattr(self, "native_qformer", True) and ops.PROFILE is None:
             comp = self._compress_native(enc, F, Nf, qtable, qs, prompt_ids)
@@ -573,15 +635,25 @@ class VideoEncoder:
         splice = {"table": embed_tokens.weight [V, H] 16-bit on this device, "before": ids, "after": ids} the same
         launch also gathers the text embeddings, so the result is the LLM's inputs_embeds row block
         [len(before) + len(pairs) + len(after), H] with no intermediate visual tensor."""
+        import numpy as np
         tables = [Xf, comp if comp is not None else self.c.frame_seg, self.c.frame_seg]
+        p_np = pairs.cpu().numpy() if torch.is_tensor(pairs) else np.asarray(pairs, dtype=np.int32)
+        p_np = np.ascontiguousarray(p_np.reshape(-1, 2).astype(np.int32, copy=False))
         if splice is not None:
             tab = splice["table"]
             assert tab.is_cuda and tab.device == Xf.device and tab.dtype == Xf.dtype and tab.shape[1] == self.c.H, \
                 "prefill hand-off needs embed_tokens on the engine device in the engine dtype"
-            pairs = [(3, int(t)) for t in splice["before"]] + list(pairs) + [(3, int(t)) for t in splice["after"]]
+
+            def text(ids_):
+                t = np.zeros((len(ids_), 2), dtype=np.int32)
+                t[:, 0] = 3
+                t[:, 1] = np.asarray([int(v) for v in ids_], dtype=np.int32)
+                return t
+            p_np = np.concatenate([text(splice["before"]), p_np, text(splice["after"])], 0)
             tables.append(tab)
-        idx = torch.tensor(pairs, dtype=torch.int32, device=self.dev).contiguous()
-        return ops.gather_rows(tables, idx, len(pairs), self.c.H)
+        ops.check_pairs_host(p_np, [t.shape[0] if t.dim() == 2 else 1 for t in tables])
+        idx = torch.from_numpy(p_np).to(self.dev)
+        return ops.gather_rows(tables, idx, idx.shape[0], self.c.H, validated=True)
 
     def compress(self, X, T, N, seg_indices, prompt_ids, max_visual_len, audio=None, keep=None, splice=None):
         """X [T*N, Hp] -> emitted visual tokens [n, H] (tdc/cambrian_arch.py:1520-1709)."""
@@ -589,11 +661,11 @@ class VideoEncoder:
 
     # ------------------------------------------------------------------------------------------------ top level
     def encode_video(self, px_siglip, px_dino, image_size, budget_text_len, n_text_tokens, prompt_ids, audio=None,
-                     frame_cap=224, keep=None, splice=None):
+                     frame_cap=224, keep=None, splice=None, video_index=None):
         """One video: pixels -> emitted visual tokens [n, H] (S0-S10).  `budget_text_len` is the text length used by
         get_max_num_frames (cambrian_arch.py:753-759), `n_text_tokens` the non-image token count (:1499-1505)."""
         return encode_video_with(self, px_siglip, px_dino, image_size, budget_text_len, n_text_tokens, prompt_ids,
-                                 audio, frame_cap, keep, splice)
+                                 audio, frame_cap, keep, splice, video_index)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -611,14 +683,7 @@ def compress_with(e, X, T, N, seg_indices, prompt_ids, max_visual_len, audio=Non
         else:
             qtable, qsrc = e.make_queries(Xf, N, Nf, plan["key_frames"]), plan["comp_chunk"]
         comp = e.compress_frames(Xf, Nf, plan["comp_frames"], qtable, qsrc, prompt_ids, keep)
-    pairs = []
-    for en in plan["src"]:
-        if en[0] == "f":
-            pairs.append((0, en[1] * Nf + en[2]))
-        elif en[0] == "c":
-            pairs.append((1, en[1] * K + en[2]))
-        else:
-            pairs.append((2, 0))
+    pairs = seg.emit_pairs(plan, Nf, K)
     if keep is not None:
         keep["plan"] = plan
         keep["n_visual"] = len(pairs)
@@ -627,8 +692,27 @@ def compress_with(e, X, T, N, seg_indices, prompt_ids, max_visual_len, audio=Non
     return e.emit(Xf, comp, pairs)
 
 
+def sample_indicator(T0, idx, video_index=None):
+    """`sample_indices` of tdc/cambrian_arch.py:916-930: one 0/1 entry per second of the video's audio, 1 where a frame
+    that survives the a1 cap was sampled.  video_index = the caller's `video_indices[i]` (0/1 per second, 1 = a frame was
+    decoded there; None: input frame t is second t)."""
+    if video_index is None:
+        samp = [0] * T0
+        for i in idx:
+            samp[i] = 1
+        return samp
+    vi = [int(v) for v in (video_index.tolist() if hasattr(video_index, "tolist") else video_index)]
+    if len(idx) == T0:
+        return vi
+    pos = [i for i, v in enumerate(vi) if v == 1]
+    samp = [0] * len(vi)
+    for i in idx:
+        samp[pos[i]] = 1
+    return samp
+
+
 def encode_video_with(e, px_siglip, px_dino, image_size, budget_text_len, n_text_tokens, prompt_ids, audio=None,
-                      frame_cap=224, keep=None, splice=None):
+                      frame_cap=224, keep=None, splice=None, video_index=None):
     cfg = e.cfg
     T0 = px_siglip.shape[0]
     idx = seg.uniform_indices(T0, min(seg.get_max_num_frames(budget_text_len, cfg), frame_cap))     # a1
@@ -647,6 +731,7 @@ def encode_video_with(e, px_siglip, px_dino, image_size, budget_text_len, n_text
             sig_early = e.tower("siglip", px_siglip)
     dino = e.tower("dino", px_dino)                                                                 # a4
     mns = cfg.get("max_num_segments", 24)
+    sig = None
     if T <= mns + 1:                                                                                # a5
         sel2, seg_idx = list(range(T)), list(range(T))
     else:
@@ -657,30 +742,25 @@ def encode_video_with(e, px_siglip, px_dino, image_size, budget_text_len, n_text
             dino = dino.view(T, P, -1)[s2].reshape(len(sel2) * P, -1)
             px_siglip = px_siglip[s2]
             T = len(sel2)
-        sims = e.sims_tensor(dino, T).tolist()
-        seg_idx = seg.select_segments(sims, mns)
+        sims_dev = e.sims_tensor(dino, T)
+        if side is None:
+            # the SigLIP tower does not depend on the selection: enqueue it BEFORE the one host read of the similarities,
+            # so the device keeps working while the host ranks them (a3)
+            sig = e.tower("siglip", px_siglip)
+        seg_idx = seg.select_segments(sims_dev.tolist(), mns)
     if side is not None:
         torch.cuda.current_stream().wait_stream(side)
         sig = sig_early
         sig.record_stream(torch.cuda.current_stream())
-    else:
+    elif sig is None:
         sig = e.tower("siglip", px_siglip)                                                          # a3
     sizes = [tuple(image_size)] * T
     X, final_size = e.connector(sig, dino, T, sizes, keep)                                          # a6-a10
     N = X.shape[0] // T
     max_visual_len = cfg["tokenizer_model_max_length"] - cfg.get("inference_max_length", 16) - n_text_tokens
     pid = prompt_ids if cfg.get("text_input", True) else None
-    if isinstance(audio, dict):                                                                     # a20
-        if audio.get("audio_tokens") is not None:
-            audio = audio["audio_tokens"]
-        else:
-            samp = [0] * T0
-            for i in idx:
-                samp[i] = 1
-            wins = audio.get("beats_windows")
-            if wins is None:                                   # raw 16 kHz waveform: BEATs on the device (8(f)-1)
-                wins = e.beats_windows(audio["audio_wav"], audio.get("audio_wav_mask"))
-            audio = e.audio_tokens(wins, samp, T)
+    if audio is not None:                                                                           # a20
+        audio = e.local_audio(audio, sample_indicator(T0, idx, video_index), T, 0, T)
     vis = compress_with(e, X, T, N, seg_idx, pid, max_visual_len, audio, keep, splice)              # a11-a19 (+a21)
     if keep is not None:
         keep.update(frame_indices=idx, selected=sel2, seg_indices=seg_idx, siglip_feat=sig, dino_feat=dino,

@@ -95,36 +95,85 @@ def unpad_newline_map(side, image_size, frame, newline_table=1, newline_row=0, f
     return src, (r1 - r0, c1 - c0)
 
 
+class Plan(dict):
+    """emit_plan's result: a dict (chunks, comp_frames, comp_chunk, key_frames) plus the token stream as three numpy
+    int arrays of equal length - kind (0 frame token, 1 context token, 2 separator), a (frame / compressed-frame index), b
+    (token index) - and, on first access only, plan["src"]: the same stream as a list of ('f', frame, tok) / ('c',
+    comp_idx, k) / ('s',) tuples (tests and small cases; a 512-frame video has ~75 k entries)."""
+
+    def __missing__(self, key):
+        if key != "src":
+            raise KeyError(key)
+        v = [("f", a, b) if k == 0 else ("c", a, b) if k == 1 else ("s",)
+             for k, a, b in zip(self.kind.tolist(), self.a.tolist(), self.b.tolist())]
+        self["src"] = v
+        return v
+
+    def __len__(self):          # number of ordinary keys; the stream length is len(plan.kind)
+        return dict.__len__(self)
+
+
 def emit_plan(T, N, K, seg_indices, max_visual_len, add_static=True):
-    """Token layout of tdc/cambrian_arch.py:1603-1709 (add_sep is hard-wired True at :1512): returns
+    """Token layout of tdc/cambrian_arch.py:1603-1709 (add_sep is hard-wired True at :1512): returns a Plan with
        chunks          [(start,end)]
        comp_frames     frame index of every compressed frame, in emission order
        comp_chunk      for each compressed frame the index (among chunks that run the Q-Former) of its chunk
        key_frames      key frame index of every chunk that runs the Q-Former
-       src             list of (kind, a, b): ('f', frame, tok) static token, ('c', comp_idx, k) context token, ('s',)
-                        frame separator - after the per-chunk tail clipping and the final [:max_visual_len] cut.
+       .kind/.a/.b     the emitted stream (see Plan) after the per-chunk tail clipping and the final [:max_visual_len] cut
     add_static=False (:1625-1628, :1686-1690): no static tokens; every frame of every chunk, the key frame and
     single-frame chunks included, is compressed."""
+    import numpy as np
     chunks = chunk_table(T, seg_indices)
     comp_frames, comp_chunk, key_frames = [], [], []
-    per_chunk = []
+    ar_n, ar_k = np.arange(N, dtype=np.int64), np.arange(K, dtype=np.int64)
+    z1 = np.zeros(1, dtype=np.int64)
+    kinds, aa, bb = [], [], []          # one array triple per chunk
     for (s, e) in chunks:
-        toks = [("f", s, t) for t in range(N)] + [("s",)] if add_static else []
+        k_parts, a_parts, b_parts = [], [], []
+        if add_static:
+            k_parts += [np.zeros(N, dtype=np.int64), z1 + 2]
+            a_parts += [np.full(N, s, dtype=np.int64), z1]
+            b_parts += [ar_n, z1]
         if e - s > 1 or not add_static:
             ci = len(key_frames)
             key_frames.append(s)
-            for f in range(s + 1 if add_static else s, e):
-                idx = len(comp_frames)
-                comp_frames.append(f)
-                comp_chunk.append(ci)
-                toks += [("c", idx, k) for k in range(K)] + [("s",)]
-        per_chunk.append(toks)
-    total = sum(len(t) for t in per_chunk)
+            f0 = s + 1 if add_static else s
+            nf = e - f0
+            if nf > 0:
+                i0 = len(comp_frames)
+                comp_frames.extend(range(f0, e))
+                comp_chunk.extend([ci] * nf)
+                blk_k = np.concatenate([np.ones(K, dtype=np.int64), z1 + 2])
+                blk_b = np.concatenate([ar_k, z1])
+                k_parts.append(np.tile(blk_k, nf))
+                b_parts.append(np.tile(blk_b, nf))
+                a_parts.append(np.repeat(np.arange(i0, i0 + nf, dtype=np.int64), K + 1))
+        kinds.append(np.concatenate(k_parts) if k_parts else np.zeros(0, dtype=np.int64))
+        aa.append(np.concatenate(a_parts) if a_parts else np.zeros(0, dtype=np.int64))
+        bb.append(np.concatenate(b_parts) if b_parts else np.zeros(0, dtype=np.int64))
+    total = sum(len(k) for k in kinds)
     if total > max_visual_len:
-        rm = math.ceil((total - max_visual_len) / len(per_chunk))
-        per_chunk = [t[:-rm] for t in per_chunk]
-    src = [x for t in per_chunk for x in t][:max_visual_len]
-    return dict(chunks=chunks, comp_frames=comp_frames, comp_chunk=comp_chunk, key_frames=key_frames, src=src)
+        rm = math.ceil((total - max_visual_len) / len(kinds))
+        # python's t[:-rm]: an empty result when rm >= len(t)
+        kinds = [k[:-rm] for k in kinds]
+        aa = [a[:-rm] for a in aa]
+        bb = [b[:-rm] for b in bb]
+    cat = lambda xs: (np.concatenate(xs) if xs else np.zeros(0, dtype=np.int64))[:max(0, max_visual_len)]
+    plan = Plan(chunks=chunks, comp_frames=comp_frames, comp_chunk=comp_chunk, key_frames=key_frames)
+    plan.kind, plan.a, plan.b = cat(kinds), cat(aa), cat(bb)
+    plan.a = np.where(plan.kind == 2, 0, plan.a)
+    plan.b = np.where(plan.kind == 2, 0, plan.b)
+    return plan
+
+
+def emit_pairs(plan, Nf, K):
+    """(table, row) gather pairs of a Plan as an int32 numpy array [n, 2]: table 0 = frame tokens (row = frame * Nf + tok),
+    1 = context tokens (row = comp_idx * K + k), 2 = the frame separator (row 0)."""
+    import numpy as np
+    out = np.zeros((len(plan.kind), 2), dtype=np.int32)
+    out[:, 0] = plan.kind
+    out[:, 1] = np.where(plan.kind == 0, plan.a * Nf + plan.b, np.where(plan.kind == 1, plan.a * K + plan.b, 0))
+    return out
 
 
 def audio_plan(window_sizes, sample_indices, dist=10):

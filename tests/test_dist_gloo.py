@@ -18,10 +18,11 @@ class FakeEngine:
     """Per-frame deterministic arithmetic standing in for the HIP engine (same interface as VideoEncoder)."""
     dtype = torch.float32
 
-    def __init__(self, K=3, H=8, P=4, N=5, max_len=10 ** 9):
+    def __init__(self, K=3, H=8, P=4, N=5, max_len=10 ** 9, **cfg):
         self.K, self.H, self.P, self.N = K, H, P, N
         self.cfg = dict(tokenizer_model_max_length=max_len, context_token_num=K, max_num_segments=24,
                         hidden_size=H)
+        self.cfg.update(cfg)
 
     def tower(self, name, px):  # px [B, 3, 2, 2] -> [B*P, H]
         B = px.shape[0]
@@ -37,12 +38,34 @@ class FakeEngine:
         X = x[:, None, :] + torch.arange(self.N).float()[None, :, None]
         return X.reshape(T * self.N, self.H), [(1, self.N - 1)] * T
 
+    def local_audio(self, audio, sample_indices, T, lo=0, hi=None):
+        """audio = {"per_second": [S, Na, H]}: the token block of kept frame i is the mean over the seconds that a1 folds
+        into it (its own second and the dropped ones that follow) - a stand-in for a20 that, like a20, depends on
+        `sample_indices` and is local to the frame."""
+        if audio is None:
+            return None
+        sec = audio["per_second"]
+        kept = [i for i, v in enumerate(sample_indices) if v == 1]
+        out = []
+        for j in range(lo, T if hi is None else hi):
+            a = kept[j]
+            b = kept[j + 1] if j + 1 < len(kept) else len(sample_indices)
+            out.append(sec[a:b].mean(0))
+        return torch.stack(out) if out else sec[0:0]
+
     def with_audio(self, X, T, N, audio):
-        return X, N
+        if audio is None:
+            return X, N
+        Na = audio.shape[1]
+        Xf = torch.cat([X.reshape(T, N, self.H), audio * 0.25], 1)
+        return Xf.reshape(T * (N + Na), self.H), N + Na
 
     def make_queries(self, Xf, N, Nf, key_rows):
         rows = [Xf[r * Nf:(r * Nf + N)].mean(0, keepdim=True) + torch.arange(self.K).float()[:, None] for r in key_rows]
         return torch.cat(rows, 0)
+
+    def learned_queries(self):
+        return torch.arange(self.K * self.H).float().reshape(self.K, self.H) * 0.01
 
     def query_width(self):
         return self.H
@@ -51,13 +74,14 @@ class FakeEngine:
         out = []
         for f, q in zip(frame_rows, qsrc):
             enc = Xf[f * Nf:(f + 1) * Nf]
-            out.append(qtable[q * self.K:(q + 1) * self.K] * 2.0 - enc.mean(0, keepdim=True))
+            out.append(qtable[q * self.K:(q + 1) * self.K] * 2.0 - enc.mean(0, keepdim=True)
+                       + (0.0 if prompt_ids is None else 0.125 * len(prompt_ids)))
         return torch.cat(out, 0)
 
-    def emit(self, Xf, comp, pairs):
+    def emit(self, Xf, comp, pairs, splice=None):
         sep = torch.full((1, self.H), -7.0)
         tabs = [Xf, comp if comp is not None else sep, sep]
-        return torch.stack([tabs[k][r] for k, r in pairs]) if pairs else torch.zeros(0, self.H)
+        return torch.stack([tabs[int(k)][int(r)] for k, r in pairs]) if len(pairs) else torch.zeros(0, self.H)
 
 
 def make_video(T):
@@ -71,17 +95,53 @@ def make_video(T):
     return torch.stack(fr)
 
 
-def _worker(rank, world, port, T, max_len, N, q):
+CASES = {
+    # name: (T0, tokenizer_model_max_length, N, cfg overrides, audio?, frame_cap)
+    "plain61": (61, 10 ** 9, 5, {}, False, 10 ** 6),
+    "plain40": (40, 10 ** 9, 5, {}, False, 10 ** 6),
+    "passthrough20": (20, 10 ** 9, 5, {}, False, 10 ** 6),               # T <= 25: every frame static, no Q-Former
+    "clip61": (61, 1250, 50, {}, False, 10 ** 6),                         # a19 tail clipping active, a1 cap not
+    "learned61": (61, 10 ** 9, 5, {"query_type": "learned"}, False, 10 ** 6),
+    "nostatic40": (40, 10 ** 9, 5, {"add_static": False}, False, 10 ** 6),
+    "notext61": (61, 10 ** 9, 5, {"text_input": False}, False, 10 ** 6),
+    "audio61": (61, 10 ** 9, 5, {"audio_input": True}, True, 10 ** 6),
+    "cap90": (90, 10 ** 9, 5, {}, False, 37),                             # a1 cap: 90 frames -> 37 kept
+    "cap90_audio": (90, 10 ** 9, 5, {"audio_input": True}, True, 37),     # ... dropped seconds folded into kept frames
+    "budget120": (120, 20 + 4 + 16 + 3 * 30, 5, {}, False, 10 ** 6),      # a1 budget (get_max_num_frames) + a19 clip
+}
+
+
+def _case(name):
+    T0, max_len, N, over, with_audio, cap = CASES[name]
+    eng = FakeEngine(max_len=max_len, N=N, **over)
+    vid = make_video(T0)
+    audio = None
+    if with_audio:
+        g = torch.Generator().manual_seed(11)
+        audio = {"per_second": torch.rand(T0, 2, eng.H, generator=g)}
+    return eng, vid, audio, cap
+
+
+def _run_rank(eng, vid, audio, cap, rank, world, comm=None):
+    sh = ShardedVideoEncoder(eng, rank, world, comm=comm)
+    fp = sh.frame_plan(vid.shape[0], budget_text_len=4, frame_cap=cap)
+    return sh.encode_video(vid[fp["siglip_frames"]], vid[fp["dino_frames"]], fp["T"], (384, 384), n_text_tokens=4,
+                           prompt_ids=[1, 2], audio=audio, sample_indices=fp["sample_indices"])
+
+
+def _serial(name):
+    eng, vid, audio, cap = _case(name)
+    return pipeline.encode_video_with(eng, vid, vid, (384, 384), budget_text_len=4, n_text_tokens=4, prompt_ids=[1, 2],
+                                      audio=audio, frame_cap=cap)
+
+
+def _worker(rank, world, port, name, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        eng = FakeEngine(max_len=max_len, N=N)
-        vid = make_video(T)
-        lo, hi = seg.shard_ranges(T, world)[rank]
-        halo = 1 if rank < world - 1 else 0
-        sh = ShardedVideoEncoder(eng, rank, world)
-        out = sh.encode_video(vid[lo:hi], vid[lo:hi + halo], T, (384, 384), n_text_tokens=4, prompt_ids=[1, 2])
+        eng, vid, audio, cap = _case(name)
+        out = _run_rank(eng, vid, audio, cap, rank, world)
         q.put((rank, out.numpy()))  # by value: the worker exits before the parent reads
     finally:
         dist.destroy_process_group()
@@ -95,33 +155,80 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("T,max_len,N", [(61, 10 ** 9, 5), (40, 10 ** 9, 5), (20, 10 ** 9, 5),
-                                         (61, 1250, 50)])   # last: a19 tail clipping active, a1 cap not
-def test_sharded_equals_serial_world2(T, max_len, N):
+@pytest.mark.parametrize("name", ["plain61", "passthrough20", "clip61", "learned61", "cap90_audio", "budget120"])
+def test_sharded_equals_serial_world2(name):
+    """two processes over gloo: the product transport (TorchComm) end to end"""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, T, max_len, N, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = {r: torch.from_numpy(a) for r, a in (q.get(timeout=120) for _ in range(world))}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    eng = FakeEngine(max_len=max_len, N=N)
-    vid = make_video(T)
-    want = pipeline.encode_video_with(eng, vid, vid, (384, 384), budget_text_len=4, n_text_tokens=4, prompt_ids=[1, 2],
-                                      frame_cap=10 ** 6)
-    if max_len < 10 ** 9:
-        full = pipeline.compress_with(FakeEngine(N=N), *eng.connector(eng.tower("siglip", vid), eng.tower("dino", vid),
-                                                                       T, None)[:1], T, N,
-                                      seg.select_segments(eng.sims_tensor(eng.tower("dino", vid), T).tolist(), 24),
+    want = _serial(name)
+    if name == "clip61":
+        eng, vid, _, _ = _case(name)
+        full = pipeline.compress_with(FakeEngine(N=eng.N), *eng.connector(eng.tower("siglip", vid), eng.tower("dino", vid),
+                                                                           61, None)[:1], 61, eng.N,
+                                      seg.select_segments(eng.sims_tensor(eng.tower("dino", vid), 61).tolist(), 24),
                                       [1, 2], 10 ** 9)
-        assert want.shape[0] <= max_len - 16 - 4 < full.shape[0]     # the a19 clip really happened
+        assert want.shape[0] <= 1250 - 16 - 4 < full.shape[0]     # the a19 clip really happened
     for r in range(world):
         assert res[r].shape == want.shape
         assert torch.equal(res[r], want), "rank %d differs" % r
+
+
+def _threads(name, world):
+    import threading
+    from util import ThreadComm
+    hub = ThreadComm.Hub(world)
+    out, err = [None] * world, []
+
+    def run(r):
+        try:
+            eng, vid, audio, cap = _case(name)
+            out[r] = _run_rank(eng, vid, audio, cap, r, world, comm=ThreadComm(hub, r))
+        except BaseException as ex:      # noqa: BLE001 - release the peers, report in the main thread
+            err.append((r, ex))
+            hub.bar.abort()
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    real = [e for e in err if not isinstance(e[1], threading.BrokenBarrierError)]
+    assert not err, real or err
+    return out
+
+
+@pytest.mark.parametrize("world", [3, 4, 8])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_sharded_equals_serial_any_world(name, world):
+    """every configuration x world size through the in-process transport (same ShardedVideoEncoder code, threads as
+    ranks): 8 ranks incl. ranks that own no key frame, chunks that straddle two boundaries, ranks without compressed frames"""
+    want = _serial(name)
+    for r, got in enumerate(_threads(name, world)):
+        assert got.shape == want.shape and torch.equal(got, want), "rank %d of %d differs" % (r, world)
+
+
+def test_cases_exercise_what_they_claim():
+    eng, vid, audio, cap = _case("cap90_audio")
+    sh = ShardedVideoEncoder(eng, 1, 4, comm=object())
+    fp = sh.frame_plan(90, 4, cap)
+    assert fp["T"] == 37 and sum(fp["sample_indices"]) == 37 and len(fp["sample_indices"]) == 90
+    assert fp["dino_frames"][:-1] == fp["siglip_frames"] and len(fp["dino_frames"]) == len(fp["siglip_frames"]) + 1
+    eng, vid, _, cap = _case("budget120")
+    assert seg.get_max_num_frames(4, eng.cfg) < 120                 # the token budget, not frame_cap, limits the frames
+    # with a video_index (decoded frames sit on a subset of the seconds) the kept seconds follow it
+    vi = [1 if i % 2 == 0 else 0 for i in range(180)]
+    eng = _case("cap90")[0]
+    fp = ShardedVideoEncoder(eng, 0, 2, comm=object()).frame_plan(90, 4, 37, video_index=vi)
+    assert len(fp["sample_indices"]) == 180 and sum(fp["sample_indices"]) == 37
+    assert all(vi[i] == 1 for i, v in enumerate(fp["sample_indices"]) if v == 1)
 
 
 def test_split_plan_partitions_the_stream():

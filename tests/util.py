@@ -42,3 +42,41 @@ def pipeline_cfg(other):
     cfg = json.loads(str(other["cfg_json"]))
     cfg.update(dino_heads=4, siglip_heads=4, qformer_heads=4)
     return cfg
+
+
+class ThreadComm:
+    """In-process transport with the interface of tdc_video_amd.dist.TorchComm: `world` threads of ONE process exchange
+    tensors through shared slots and barriers.  Test infrastructure only: it lets a one-GPU box (which admits at most six
+    GPU processes) rehearse the data flow of an 8-rank job; the product transport is torch.distributed."""
+
+    class Hub:
+        def __init__(self, world):
+            import threading
+            self.world = world
+            self.bar = threading.Barrier(world)
+            self.slots = [None] * world
+            self.mail = {}
+            self.lock = threading.Lock()
+
+    def __init__(self, hub, rank):
+        self.hub, self.rank, self.world = hub, rank, hub.world
+
+    def all_gather(self, t):
+        h = self.hub
+        h.slots[self.rank] = t.clone()
+        h.bar.wait()
+        out = [s.clone() for s in h.slots]
+        h.bar.wait()
+        return out
+
+    def exchange(self, sends, recvs):
+        h = self.hub
+        with h.lock:
+            for t, dst in sends:
+                h.mail.setdefault((self.rank, dst), []).append(t.clone())
+        h.bar.wait()
+        for buf, src in recvs:
+            with h.lock:
+                t = h.mail[(src, self.rank)].pop(0)
+            buf.copy_(t)
+        h.bar.wait()

@@ -33,10 +33,10 @@ def main():
         res = []
         for dbg in (None, "1"):
             if dbg:
-                os.environ["TDC_GEMM_DEBUG"] = dbg
+                L.load().tdc_gemm_set_debug(int(dbg))
             t16 = timeit(lambda: ops.gemm(x16, w16, b, act=act, out=out), iters=10)
             t8 = timeit(lambda: ops.gemm(x8, w8, b, act=act, out=out, ln_stats=stats, ln_c1=c1, out_dtype=dt), iters=10)
-            os.environ.pop("TDC_GEMM_DEBUG", None)
+            L.load().tdc_gemm_set_debug(0)
             res.append((t16, t8))
         t88 = None
         if name.endswith("fc1"):    # e4m3 output with analytic row scales (tdc_gemm_desc.out_fp8, fp8 level 3)

@@ -1,9 +1,9 @@
-"""Same-process A/B of a TDC_GEMM_DEBUG-switched kernel experiment on tower GEMM shapes (alternating runs, 3 rounds):
+"""Same-process A/B of a tdc_gemm_set_debug()-switched kernel experiment on tower GEMM shapes (alternating runs, 3 rounds):
 python tools/bench_gemm_ab.py <debug value> rmw|plain"""
 import math, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tdc_video_amd  # noqa
-from tdc_video_amd import ops
+from tdc_video_amd import ops, lib as L
 from tools.bench_ops import timeit
 frames, flag, kind = 256, sys.argv[1], sys.argv[2]
 g = torch.Generator(device="cuda").manual_seed(0)
@@ -23,8 +23,7 @@ for name, S, N, K in shapes:
     res = []
     for rep in range(3):
         for dbg in (None, flag):
-            if dbg: os.environ["TDC_GEMM_DEBUG"] = dbg
-            else: os.environ.pop("TDC_GEMM_DEBUG", None)
+            L.load().tdc_gemm_set_debug(int(dbg) if dbg else 0)
             res.append(timeit(fn, iters=10))
-    os.environ.pop("TDC_GEMM_DEBUG", None)
+    L.load().tdc_gemm_set_debug(0)
     print(name, " base: %s  switched: %s" % (["%.3f" % t for t in res[0::2]], ["%.3f" % t for t in res[1::2]]), flush=True)

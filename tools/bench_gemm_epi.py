@@ -1,5 +1,5 @@
 """Per tower-GEMM type (real epilogue: fp32 residual RMW / GELU / SwiGLU / plain 16-bit): time of the whole kernel vs the
-same launch with the epilogue skipped (TDC_GEMM_DEBUG=1), i.e. the share of the C-tile drain.  bf16, one MI355X."""
+same launch with the epilogue skipped (tdc_gemm_set_debug(1)), i.e. the share of the C-tile drain.  bf16, one MI355X."""
 import math
 import os
 import sys
@@ -39,15 +39,15 @@ def main():
         else:
             out = torch.empty(M, n_out, device="cuda", dtype=dtype)
             fn = lambda: ops.gemm(a, w, bias=bias, act=act, out=out)
-        os.environ.pop("TDC_GEMM_DEBUG", None)
+        L.load().tdc_gemm_set_debug(0)
         timeit(fn, iters=10)          # the first timed batch on fresh buffers runs 10-13 % slow (first touch): discard it
         ms = ms0 = 1e9
         for _ in range(2):            # alternate the two forms, keep the better of two batches each
-            os.environ.pop("TDC_GEMM_DEBUG", None)
+            L.load().tdc_gemm_set_debug(0)
             ms = min(ms, timeit(fn, iters=10))
-            os.environ["TDC_GEMM_DEBUG"] = "1"
+            L.load().tdc_gemm_set_debug(1)
             ms0 = min(ms0, timeit(fn, iters=10))
-        os.environ.pop("TDC_GEMM_DEBUG", None)
+        L.load().tdc_gemm_set_debug(0)
         fl = 2.0 * M * N * K
         layers = 27 if name.startswith("siglip") else 40
         tot[0] += ms * layers; tot[1] += ms0 * layers

@@ -22,6 +22,7 @@ static void fill_bf16(std::vector<unsigned short>& v, unsigned seed, float scale
 }
 
 int main(int argc, char** argv) {
+    if (const char* e = getenv("TDC_GEMM_DEBUG")) tdc_gemm_set_debug(atoi(e));   // the tool, not the library, reads the environment
     if (argc < 2) { fprintf(stderr, "usage: gemm_pmc shapes.txt [reps]\n"); return 2; }
     int reps = argc > 2 ? atoi(argv[2]) : 2;
     const bool fp8 = getenv("TDC_PMC_FP8") != nullptr;      // e4m3 operands (K % 128 == 0 shapes only; others are skipped)

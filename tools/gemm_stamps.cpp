@@ -22,6 +22,7 @@ static void fill_bf16(std::vector<unsigned short>& v, unsigned seed, float scale
 }
 
 int main(int argc, char** argv) {
+    if (const char* e = getenv("TDC_GEMM_DEBUG")) tdc_gemm_set_debug(atoi(e));   // the tool, not the library, reads the environment
     if (argc < 7) { fprintf(stderr, "usage: gemm_stamps M N K act res outf32 [reps]\n"); return 2; }
     int M = atoi(argv[1]), N = atoi(argv[2]), K = atoi(argv[3]), act = atoi(argv[4]), res = atoi(argv[5]), outf32 = atoi(argv[6]);
     int reps = argc > 7 ? atoi(argv[7]) : 3;
