@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16/fp16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PMC_SUMMARY = "r02_gemm_pmc_summary.json"   # profiles/: counters of the current code (tools/run_gemm_pmc.sh), see `traffic_source`
 
 
 def model_cfg(H, K, T):
@@ -222,7 +223,6 @@ def main():
     enc.two_streams = bool(args.two_streams)
     wav = None
     if args.audio:
-        assert world == 1, "--audio: single-GPU workload"
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         from bench_beats import random_beats_state
         from tdc_video_amd.beats import BEATS_ITER3_CFG, BeatsEncoder
@@ -231,7 +231,9 @@ def main():
         enc.c.audio_proj = Wt.make_lin(torch.randn(H, 768, device=dev, generator=gen) * 0.02,
                                        torch.zeros(H, device=dev), dtype, dev)
         enc.beats = BeatsEncoder(random_beats_state(BEATS_ITER3_CFG), BEATS_ITER3_CFG, dtype=dtype, device=dev)
-        wav = (0.1 * torch.randn(1, 16000 * T, device=dev, generator=gen)).half()      # 1 frame per second
+        # 1 frame per second; every rank holds the waveform (16 MB at T = 512) and encodes only its own 10-s windows
+        gw = torch.Generator(device=dev).manual_seed(77)
+        wav = (0.1 * torch.randn(1, 16000 * T, device=dev, generator=gw)).half()
     sd_cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sd_cpu = {k: v.cpu() for k, v in sd.items()}
@@ -255,7 +257,8 @@ def main():
         sharded = tdist.ShardedVideoEncoder(enc, rank, world)
 
         def step():
-            return sharded.encode_video(vs, vd, T, (384, 384), n_text_tokens=64, prompt_ids=prompt_ids)
+            return sharded.encode_video(vs, vd, T, (384, 384), n_text_tokens=64, prompt_ids=prompt_ids,
+                                        audio={"audio_wav": wav} if wav is not None else None)
 
     def barrier():
         if world > 1:
@@ -283,7 +286,12 @@ def main():
     torch.cuda.synchronize()
     prof = ops.PROFILE
     ops.PROFILE = None
+    this_args = dict(frames=T, K=K, hidden=H, gpus=world, tower_batch=args.tower_batch, dtype=args.dtype, px=args.px,
+                     audio=bool(args.audio), fp8_level=args.fp8_level if args.dtype == "fp8" else 0,
+                     two_streams=int(args.two_streams))
     if args.dump_gemm_shapes and rank == 0:
+        with open(args.dump_gemm_shapes + ".args.json", "w") as fh:
+            json.dump(this_args, fh)
         import collections
         cnt = collections.Counter(prof["gemm_shapes"])
         with open(args.dump_gemm_shapes, "w") as fh:
@@ -296,29 +304,39 @@ def main():
     # the north_star's cross-attention block = the stacked K/V projection GEMM (+ tiny QK^T/PV): report it separately
     kv = [(e0.elapsed_time(e1), w) for e0, e1, w in prof["gemm"] if abs(w - max(x[2] for x in prof["gemm"])) < 1]
     achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
-    # HBM-side traffic per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction), collected on the
-    # same GEMM launch list by the torch-free driver tools/gemm_pmc.cpp (rocprofv3 --pmc segfaults inside a torch
-    # process on this image) and committed under profiles/; null when that summary is absent or another workload runs.
-    traffic = mfma_busy = kv_busy = None
-    pmc = os.path.join(ROOT, "profiles", "r01e_gemm_pmc_summary.json")
-    if os.path.exists(pmc) and (T, K, H, world, args.tower_batch, args.dtype) == (512, 144, 3584, 1, 512, "bf16"):
+    # HBM-side traffic per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction).  They cannot be
+    # collected inside this process (rocprofv3 --pmc segfaults in a torch process on this image), so they come from a
+    # committed summary that the torch-free replay tools/gemm_pmc.cpp produced on this bench's own GEMM launch list
+    # (tools/run_gemm_pmc.sh).  The summary names the command line and the commit it was collected at; it is used only
+    # when this run's arguments match that command line, and the line says where the numbers come from - otherwise null.
+    traffic = mfma_busy = kv_busy = traffic_source = None
+    pmc = os.path.join(ROOT, "profiles", PMC_SUMMARY)
+    if os.path.exists(pmc):
         summ = json.load(open(pmc))
-        traffic = round(summ["per_launch_hbm_bytes"])
-        # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles) over the same launch list: MFMA pipe occupancy at the
-        # clock the chip actually holds (it drops to ~1.9 GHz under this load, so this reads higher than `frac`)
-        mfma_busy = summ.get("mfma_busy_frac")
-        kv_busy = max((r.get("mfma_busy_frac", 0) for r in summ["shapes"] if r["N"] >= 9216 and r["K"] == H), default=None)
+        if summ.get("bench_args") == this_args:
+            traffic = round(summ["per_launch_hbm_bytes"])
+            # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles) over the same launch list: MFMA pipe occupancy at the
+            # clock the chip actually holds (it drops to ~1.9 GHz under this load, so this reads higher than `frac`)
+            mfma_busy = summ.get("mfma_busy_frac")
+            kv_busy = max((r.get("mfma_busy_frac", 0) for r in summ["shapes"] if r["N"] >= 9216 and r["K"] == H), default=None)
+            traffic_source = "replayed, not measured in this run: profiles/%s (tools/gemm_pmc.cpp on this launch list, " \
+                             "collected at commit %s)" % (PMC_SUMMARY, summ.get("collected_at_commit", "?"))
     # fp8 runs: the dense f8f6f4 MFMA peak (5 PFLOP/s) when every tower GEMM runs on e4m3 operands (level 2); at level 1
     # a third of the GEMM FLOPs stay in bf16, the bf16 peak is kept as the (conservative) yardstick
     peak = 2.0 * MFMA_PEAK_TFLOPS if (args.dtype == "fp8" and args.fp8_level >= 2) else MFMA_PEAK_TFLOPS
+    a_tf = a_fl / (a_ms * 1e-3) / 1e12 if a_ms > 0 else None
+    # whole step: every algorithmic FLOP of the pass (GEMMs + attention; the rest is byte work) over the TIMED step time
+    step_tf = (g_fl + a_fl) / (ms_per_step * 1e-3) / 1e12 * (world if world > 1 else 1)
     roofline = dict(bound="mfma", achieved=round(achieved, 1), peak=peak, unit="TFLOP/s",
-                    frac=round(achieved / peak, 4), traffic=traffic,
+                    frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_source,
                     kernel="gemm256p_kernel / gemm256_kernel / gemm_kernel (tdc_gemm)",
                     launches=len(prof["gemm"]), avg_launch_us=round(g_ms * 1e3 / max(1, len(prof["gemm"])), 2),
                     gemm_ms_per_step=round(g_ms, 2), gemm_tflop_per_step=round(g_fl / 1e12, 2),
-                    attention=dict(ms_per_step=round(a_ms, 2),
-                                   tflops=round(a_fl / (a_ms * 1e-3) / 1e12, 1) if a_ms > 0 else None,
+                    attention=dict(ms_per_step=round(a_ms, 2), tflops=round(a_tf, 1) if a_tf else None,
+                                   frac=round(a_tf / MFMA_PEAK_TFLOPS, 4) if a_tf else None,
                                    launches=len(prof["attn"])),
+                    whole_step=dict(tflops=round(step_tf, 1), frac=round(step_tf / (peak * world), 4),
+                                    note="(GEMM + attention FLOPs of this rank x ranks) / timed step; peak x ranks"),
                     xattn_kv_gemm_tflops=round(sum(w for _, w in kv) / (sum(t for t, _ in kv) * 1e-3) / 1e12, 1)
                     if kv else None, mfma_busy_pmc=mfma_busy, xattn_kv_mfma_busy_pmc=kv_busy)
     if rank != 0:
@@ -333,7 +351,7 @@ def main():
                                "random-init weights, frame cap lifted to T, LLM stubbed%s"
                                % (T, px_s, px_d, H, K, ", + %d s of 16 kHz audio through BEATs (50 audio tokens / frame in "
                                   "the Q-Former KV)" % T if args.audio else ""),
-                   "frames": T, "K": K, "hidden": H, "parallelism": "frames sharded over %d GPU(s)" % world,
+                   "frames": T, "K": K, "hidden": H, "px": px_s, "parallelism": "frames sharded over %d GPU(s)" % world,
                    "emitted_tokens": int(out.shape[0])},
         "roofline": roofline,
     }

@@ -9,7 +9,9 @@ Same class / method / argument names, config keys and error behaviour, so `Cambr
 in libtdc_hip.so through `pipeline.VideoEncoder`; this file only holds parameters (nn.Parameter containers whose
 names reproduce the reference state dict), does the host integer logic and the text/visual splice (a21).
 
-Deliberate differences (documented in DESIGN.md): the dead `Qformer.cls` LM head is not allocated; the three aux
+Deliberate differences (documented in DESIGN.md): the dead `Qformer.cls` LM head is not allocated; a sample with
+several <image> tokens raises IndexError as the reference does (it indexes past its one-entry-per-sample feature list,
+tdc/cambrian_arch.py:1716), it is not given a meaning of its own; the three aux
 return values used only by in-LLM samplers (`connector_only=False`) are returned as None; `video_indices=[None]`
 (what generate() passes) is treated as "not given" instead of raising TypeError when the frame cap triggers
 (tdc/cambrian_arch.py:919); training-only entry points raise NotImplementedError.
@@ -531,7 +533,11 @@ class CambrianMetaForCausalLM(ABC):
                 new_labels.append(lab)
                 continue
             if len(img_pos) != 1:
-                raise NotImplementedError("one <image> token per sample (one video / image per prompt)")
+                # The reference takes one entry of its per-video feature list per <image> token (cur_image_idx,
+                # tdc/cambrian_arch.py:1457-1495, :1712-1727) while that list holds one entry per sample: a sample with
+                # several <image> tokens runs off its end.  Same exception type here.
+                raise IndexError("list index out of range: %d <image> tokens in sample %d, one video / image per sample "
+                                 "(tdc/cambrian_arch.py:1716)" % (len(img_pos), i))
             p = img_pos[0]
             if spliced[i]:
                 n_vis = vis.shape[0] - (ids.shape[0] - 1)

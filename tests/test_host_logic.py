@@ -218,33 +218,12 @@ def test_early_out_returns_inputs_untouched():
 def test_checkpoint_loader_roundtrip(tmp_path):
     """8(f)-4: a released-checkpoint-style directory (sharded safetensors + index, 'model.' prefixed reference names,
     unrelated LLM tensors mixed in) fills the boundary model; towers load from HF-style directories."""
-    from safetensors.torch import save_file
     from tdc_video_amd import checkpoint as ck
+    from util import write_released_style_checkpoint
     W, o = load_fixture("pipeline_T40.npz")
-    path_sd = {"model." + k: v.contiguous() for k, v in W.items() if not k.startswith("vision_tower_aux_list")}
-    keys = sorted(path_sd)
-    half = len(keys) // 2
-    d = tmp_path / "ckpt"
-    d.mkdir()
-    shard_a = {k: path_sd[k] for k in keys[:half]}
-    shard_a["model.layers.0.self_attn.q_proj.weight"] = torch.zeros(4, 4)      # LLM tensor: must be skipped
-    shard_b = {k: path_sd[k] for k in keys[half:]}
-    shard_b["lm_head.weight"] = torch.zeros(4, 4)
-    save_file(shard_a, str(d / "model-00001-of-00002.safetensors"))
-    save_file(shard_b, str(d / "model-00002-of-00002.safetensors"))
-    wm = {k: "model-00001-of-00002.safetensors" for k in shard_a}
-    wm.update({k: "model-00002-of-00002.safetensors" for k in shard_b})
-    (d / "model.safetensors.index.json").write_text(__import__("json").dumps({"weight_map": wm}))
-    tdirs = []
-    for i, pre in enumerate(("vision_model.", "")):                              # 4.46-style prefix for SigLIP
-        td = tmp_path / ("tower%d" % i)
-        td.mkdir()
-        p = "vision_tower_aux_list.%d.vision_tower." % i
-        save_file({pre + k[len(p):]: v.contiguous() for k, v in W.items() if k.startswith(p)},
-                  str(td / "model.safetensors"))
-        tdirs.append(str(td))
+    d, sig_dir, dino_dir = write_released_style_checkpoint(W, tmp_path)
     lm = build_stub_lm(tiny_config())
-    missing, unexpected = ck.load_path_weights(lm.model, str(d), tdirs[0], tdirs[1])
+    missing, unexpected = ck.load_path_weights(lm.model, d, sig_dir, dino_dir)
     assert missing == [] and unexpected == []
     got = lm.model.tdc_state_dict()
     for k, v in W.items():

@@ -44,6 +44,42 @@ def pipeline_cfg(other):
     return cfg
 
 
+def write_released_style_checkpoint(W, root):
+    """Lay the fixture weights out the way the released checkpoints are (tdc/builder.py:168-172,243-257): a
+    directory of sharded safetensors + index whose keys carry the reference's 'model.' prefix (with unrelated LLM tensors
+    mixed in) and one HF directory per tower (transformers-4.46 'vision_model.' prefix for SigLIP, bare names for DINOv2).
+    Returns (ckpt_dir, siglip_dir, dino_dir)."""
+    from safetensors.torch import save_file
+    root = str(root)
+    path_sd = {"model." + k: v.contiguous() for k, v in W.items() if not k.startswith("vision_tower_aux_list")}
+    keys = sorted(path_sd)
+    half = len(keys) // 2
+    d = os.path.join(root, "ckpt")
+    os.makedirs(d)
+    shard_a = {k: path_sd[k] for k in keys[:half]}
+    shard_a["model.layers.0.self_attn.q_proj.weight"] = torch.zeros(4, 4)      # LLM tensor: must be skipped
+    shard_b = {k: path_sd[k] for k in keys[half:]}
+    shard_b["lm_head.weight"] = torch.zeros(4, 4)
+    save_file(shard_a, os.path.join(d, "model-00001-of-00002.safetensors"))
+    save_file(shard_b, os.path.join(d, "model-00002-of-00002.safetensors"))
+    wm = {k: "model-00001-of-00002.safetensors" for k in shard_a}
+    wm.update({k: "model-00002-of-00002.safetensors" for k in shard_b})
+    with open(os.path.join(d, "model.safetensors.index.json"), "w") as fh:
+        json.dump({"weight_map": wm}, fh)
+    tdirs = []
+    for i, pre in enumerate(("vision_model.", "")):
+        td = os.path.join(root, "tower%d" % i)
+        os.makedirs(td)
+        p = "vision_tower_aux_list.%d.vision_tower." % i
+        sd = {pre + k[len(p):]: v.contiguous() for k, v in W.items() if k.startswith(p)}
+        if i == 0:      # what the HF SigLIP checkpoint also holds and the path never reads
+            sd["vision_model.head.probe"] = torch.zeros(1, 1, 4)
+            sd["vision_model.post_layernorm.weight"] = torch.ones(4)
+        save_file(sd, os.path.join(td, "model.safetensors"))
+        tdirs.append(td)
+    return d, tdirs[0], tdirs[1]
+
+
 class ThreadComm:
     """In-process transport with the interface of tdc_video_amd.dist.TorchComm: `world` threads of ONE process exchange
     tensors through shared slots and barriers.  Test infrastructure only: it lets a one-GPU box (which admits at most six

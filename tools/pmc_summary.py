@@ -49,6 +49,13 @@ summary = dict(per_launch_hbm_bytes=tot_traffic / tot_n, per_launch_algorithmic_
                ratio=round(tot_traffic / tot_alg, 3), launches_per_step=int(tot_n), shapes=res)
 if mfma is not None:
     summary["mfma_busy_frac"] = round(mf_b / mf_c, 4)
+# provenance: the bench command line these launches belong to (written by bench.py --dump-gemm-shapes) and the commit of the
+# library the counters were collected on (TDC_COMMIT: the GPU box has no .git)
+import os
+if os.path.exists(shapes_file + ".args.json"):
+    summary["bench_args"] = json.load(open(shapes_file + ".args.json"))
+summary["collected_at_commit"] = os.environ.get("TDC_COMMIT", "unknown")
+summary["collected_by"] = "tools/run_gemm_pmc.sh (torch-free replay tools/gemm_pmc.cpp, one counter per rocprofv3 pass)"
 json.dump(summary, open(out + "/gemm_pmc_summary.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in summary.items() if k != "shapes"}))
 for r in res[:12]:
