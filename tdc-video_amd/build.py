@@ -13,7 +13,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-res
 # attention reads its S / O accumulators with VALU every KV tile: keep MFMA results in VGPRs, otherwise the compiler
 # parks them in AGPRs and pays 160 v_accvgpr moves per tile (GEMM accumulators are only read in the epilogue, AGPRs fit)
 # -fno-honor-nans: fmaxf without the canonicalising v_max x,x (scores are finite; -inf only enters through the mask)
-FILE_FLAGS = {"attention.hip": ["-mllvm", "--amdgpu-mfma-vgpr-form", "-fno-honor-nans"]}
+FILE_FLAGS = {"attention.hip": ["-mllvm", "--amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
+              "attention32.hip": ["-mllvm", "--amdgpu-mfma-vgpr-form", "-fno-honor-nans"]}
 
 
 def sources():

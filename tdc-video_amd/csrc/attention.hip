@@ -15,24 +15,12 @@
 //    patterns are bank-conflict free for d = 64/72.
 #include "common.h"
 #include "../../include/tdc_hip.h"
+#include "attention_args.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
 
 namespace {
-
-struct AttnArgs {
-    const void *q, *k, *v; void* o;
-    long long q_bs, k_bs, v_bs, o_bs;
-    int q_rs, k_rs, v_rs, o_rs;
-    int heads, d, sq, sk;
-    float scale_log2;
-    int vec_ok;
-    // additive score bias (BEATs gated relative position bias): score(b,h,q,k) += gate[(b*sq+q)*gate_rs + h] *
-    // bias[h*bias_hs + q*bias_rs + k]; both fp32, bias rows 16-byte aligned (sk % 4 == 0)
-    const float* bias; long long bias_hs; int bias_rs;
-    const float* gate; int gate_rs;
-};
 
 constexpr int KT = 64;  // keys per tile
 
@@ -381,6 +369,14 @@ extern "C" int tdc_attention(const tdc_attn_desc* d, void* stream) {
         }
     }
     hipStream_t st = (hipStream_t)stream;
+    if (d->dtype != TDC_F16 && d->dtype != TDC_BF16) return TDC_E_BADARG;
+    {   // long sequences at head dim 64 / 72 (the towers): the 32x32x16 form; TDC_ATTN32=0 keeps the 16x16x32 kernels
+        const char* e = getenv("TDC_ATTN32");      // read per call: tests and tools/bench_attn.py switch forms in one process
+        if (!e || atoi(e) != 0) {
+            const int rc = tdc_attention32(a, d->batch, d->dtype, st);
+            if (rc != -1) return rc;
+        }
+    }
     if (d->dtype == TDC_F16) return launch<f16>(a, d->batch, st);
     if (d->dtype == TDC_BF16) return launch<bf16>(a, d->batch, st);
     return TDC_E_BADARG;

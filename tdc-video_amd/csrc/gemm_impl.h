@@ -13,6 +13,9 @@ extern int tdc_gemm_debug_mode;
 
 namespace {
 
+#ifndef TDC_FAST32
+#define TDC_FAST32 1
+#endif
 constexpr int kMaxDev = 64;      // per-device caches below are indexed by hipGetDevice()
 inline int current_device() {
     int dev = 0;
@@ -31,6 +34,8 @@ struct GemmArgs {
     RowMap am, cm, rm;
     int tiles_m, tiles_n;
     int debug;   // tdc_gemm_set_debug(): 1 = skip the epilogue, 2 = direct (un-staged) epilogue - timing experiments only
+    int stagger_ticks;       // persistent kernel: start offset between the tile-column groups of an XCD, in 10-ns ticks (0 = off)
+    int stagger_xcd_ticks;   // ... and between the XCDs
     // LayerNorm fusion (see EpiOps / slot_stats_*): producer side x16 + ln_part, consumer side ln_stats + ln_c1
     void* x16; int ldx16; float* ln_part;
     const float* ln_stats; const float* ln_c1;
@@ -38,6 +43,7 @@ struct GemmArgs {
     int out_fp8; float* out_stats; float out_w2max, out_bmax, out_wscale;
 #ifdef TDC_GEMM_DIAG
     unsigned long long* stamps;   // diagnostics build only (tools/gemm_stamps.cpp): 8 x u64 per workgroup
+    unsigned long long* wstamps;  // ... per tile and WAVE (persistent kernel): 4 x u64 = epilogue start / issued / acknowledged
     int diag_mode;                // diagnostics build only, TDC_GEMM_DIAGMODE: 1 = no staging (stale LDS), 2 = no MFMAs
 #endif
 };
@@ -502,6 +508,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     epilogue<T, 4, 4>(p, acc, m0 + wm * 64, n0 + wn_ * 64, fr, g);
 }
 
+// The staged epilogues carry an interior-tile fast path beside their general form.  Both need `ops.lin(acc[i][j])`; the same
+// expression on both sides of a branch is hoisted above it - here above the whole run-time dispatch of epilogue variants -
+// into NEW registers: 128 more live values next to the 128 accumulators (measured: 300-600 spilled VGPRs).  The fast paths
+// therefore work on an opaque copy of the (16-register) column operands, which makes their arithmetic theirs alone.
+template <class OPS>
+__device__ __forceinline__ OPS opaque_ops(OPS o) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(o.bias[j]));
+    return o;
+}
+
 // ---- LDS-staged epilogue of the 256^2 kernels -------------------------------------------------------------------------
 // Row-per-lane stores straight from the MFMA layout touch 16 cache lines with 8 B each per instruction and are
 // store-ISSUE bound (~7 B/clk/CU, cdna_hip_programming.md T21): the 128 KiB C tile cost ~9 us per workgroup, 25 % of a
@@ -519,6 +536,55 @@ __device__ __forceinline__ void epi_staged16(const GemmArgs& p, f32x4 (&acc)[8][
     const int fr = lane & 15, g = lane >> 4;
     EpiOps<8, 4, LB, FOLD> ops;
     ops.load(p, mbase, nbase, fr, g, el);
+#ifdef TDC_GEMM_DIAG     // decomposition experiments (tools/run_gemm_epi_parts.sh): 8 = no global stores, 16 = no LDS staging
+    const bool diag_no_store = p.debug & 8, diag_no_stage = p.debug & 16;
+#else
+    constexpr bool diag_no_store = false, diag_no_stage = false;
+#endif
+    // Interior sub-tile with an identity c_map (every tile of the tower GEMMs but the last row / column of tiles): one running
+    // store pointer, no per-row bounds test and no row-map arithmetic, so a pass is straight-line code - its LDS reads are
+    // all in flight before the first store waits for one.  In the general form below every store sits in its own
+    // exec-masked block behind its own LDS read and (possibly) a row-map division: ~250 cycles of latency per 1-KiB store
+    // instruction, which made a wave's epilogue 4.3 us long (tools/run_gemm_epi_parts.sh).
+    if (RES == 0 && !diag_no_store && !diag_no_stage && p.cm.seg == 0 && mbase + 128 <= p.M && nbase + 64 <= p.N) {
+        const auto fops = opaque_ops(ops);
+        const int sw = fr & 7, rrow = lane >> 3, rk = lane & 7;
+        char* wbase = region + fr * 128 + (g & 1) * 8;
+        const char* rbase = region + rrow * 128 + ((rk ^ rrow) << 4);
+        T* cptr = (T*)p.C + (long long)(mbase + rrow) * p.ldc + nbase + rk * 8;
+        const long long step = 8ll * p.ldc;
+#pragma unroll
+        for (int pass = 0; pass < 128 / ROWS; ++pass) {
+#pragma unroll
+            for (int ii = 0; ii < ROWS / 16; ++ii) {
+                const int i = pass * (ROWS / 16) + ii;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v = fops.lin(acc[i][j], i, j);
+                    if (ACT == TDC_ACT_GELU_ERF) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                    } else if (ACT == TDC_ACT_GELU_TANH) {
+                        v = gelu_tanh4(v);
+                    }
+                    v4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (T)v[e];
+                    *(v4*)(wbase + ii * 2048 + (((j * 2 + (g >> 1)) ^ sw) << 4)) = o;
+                }
+            }
+            v8 val[ROWS / 8];
+#pragma unroll
+            for (int q = 0; q < ROWS / 8; ++q) val[q] = *(const v8*)(rbase + q * 1024);
+#pragma unroll
+            for (int q = 0; q < ROWS / 8; ++q) {
+                __builtin_nontemporal_store(val[q], (v8*)cptr);
+                cptr += step;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
 #pragma unroll
     for (int pass = 0; pass < 128 / ROWS; ++pass) {
 #pragma unroll
@@ -549,7 +615,8 @@ __device__ __forceinline__ void epi_staged16(const GemmArgs& p, f32x4 (&acc)[8][
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (T)v[e];
                 const int chunk = (j * 2 + (g >> 1)) ^ (r & 7);
-                *(v4*)(region + r * 128 + chunk * 16 + (g & 1) * 8) = o;
+                if (!diag_no_stage) *(v4*)(region + r * 128 + chunk * 16 + (g & 1) * 8) = o;
+                else asm volatile("" ::"v"(o));
             }
         }
         // same wave, in-order LDS queue: the reads below observe the writes above (and the next pass's writes follow
@@ -557,8 +624,11 @@ __device__ __forceinline__ void epi_staged16(const GemmArgs& p, f32x4 (&acc)[8][
 #pragma unroll
         for (int q = 0; q < ROWS / 8; ++q) {
             const int r = q * 8 + (lane >> 3), k = lane & 7;
-            const v8 val = *(const v8*)(region + r * 128 + ((k ^ (r & 7)) << 4));
+            v8 val;
+            if (!diag_no_stage) val = *(const v8*)(region + r * 128 + ((k ^ (r & 7)) << 4));
+            else { const f32x4 a0 = acc[pass][q & 3]; val = __builtin_bit_cast(v8, a0); }     // any register data, same addresses
             const int m = mbase + pass * ROWS + r, n = nbase + k * 8;
+            if (diag_no_store) { asm volatile("" ::"v"(val)); continue; }
             if (m < p.M && n < p.N) __builtin_nontemporal_store(val, (v8*)((T*)p.C + p.cm(m) * p.ldc + n));
         }
     }
@@ -575,6 +645,40 @@ __device__ __forceinline__ void epi_staged_swiglu(const GemmArgs& p, f32x4 (&acc
     const int fr = lane & 15, g = lane >> 4;
     EpiOps<8, 4, LB, FOLD> ops;
     ops.load(p, mbase, nbase, fr, g, el);
+    if (p.cm.seg == 0 && mbase + 128 <= p.M && nbase + 64 <= p.N) {      // interior sub-tile: see epi_staged16
+        const auto fops = opaque_ops(ops);
+        const int rrow = lane >> 2, rk = lane & 3;
+        char* wbase = region + fr * 64 + g * 4;
+        const int wsw = (fr >> 2) & 3;                                     // (r >> 2) & 3 with r = 16 ii + fr
+        const char* rbase = region + rrow * 64 + ((rk ^ ((rrow >> 2) & 3)) << 4);
+        T* cptr = (T*)p.C + (long long)(mbase + rrow) * p.ldc + (nbase >> 1) + rk * 8;
+        const long long step = 16ll * p.ldc;
+#pragma unroll
+        for (int pass = 0; pass < 128 / ROWS; ++pass) {
+#pragma unroll
+            for (int ii = 0; ii < ROWS / 16; ++ii) {
+                const int i = pass * (ROWS / 16) + ii;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x2_t sg = swiglu2(fops.lin(acc[i][j], i, j));
+                    v2 o;
+                    o[0] = (T)sg[0];
+                    o[1] = (T)sg[1];
+                    *(v2*)(wbase + ii * 1024 + ((j ^ wsw) << 4)) = o;
+                }
+            }
+            v8 val[ROWS / 16];
+#pragma unroll
+            for (int q = 0; q < ROWS / 16; ++q) val[q] = *(const v8*)(rbase + q * 1024);
+#pragma unroll
+            for (int q = 0; q < ROWS / 16; ++q) {
+                __builtin_nontemporal_store(val[q], (v8*)cptr);
+                cptr += step;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
 #pragma unroll
     for (int pass = 0; pass < 128 / ROWS; ++pass) {
 #pragma unroll
@@ -686,15 +790,70 @@ __device__ __forceinline__ void epi_staged32(const GemmArgs& p, f32x4 (&acc)[8][
     const int fr = lane & 15, g = lane >> 4;
     EpiOps<8, 4, LB, FOLD> ops;
     ops.load(p, mbase, nbase, fr, g, el);
+#ifdef TDC_GEMM_DIAG     // 8 = no global stores, 16 = no LDS staging, 32 = no residual loads
+    const bool diag_no_store = p.debug & 8, diag_no_stage = p.debug & 16, diag_no_res = p.debug & 32;
+#else
+    constexpr bool diag_no_store = false, diag_no_stage = false, diag_no_res = false;
+#endif
     constexpr int NPASS = 128 / ROWS, QP = ROWS / 4;      // QP read-back instructions (4 rows x 256 B each) per pass
     // The residual loads run as a ring of RING loads ahead of the read-back, independent of the staging passes (they
     // touch no LDS); they come from clamped (always valid) addresses so that no branch - and no vmcnt(0) - separates them.
+    if (TDC_FAST32 && !EMIT && !diag_no_store && !diag_no_stage && !diag_no_res && p.cm.seg == 0 && (RES == 0 || p.rm.seg == 0) &&
+        mbase + 128 <= p.M && nbase + 64 <= p.N) {
+        // interior sub-tile, identity row maps (see epi_staged16): running pointers for the residual loads and the stores, the
+        // residual ring filled up front, a pass = 4 writes, 4 read-backs, 4 stores of straight-line code
+        const auto fops = opaque_ops(ops);
+        const int rrow = lane >> 4, rk = lane & 15;
+        char* wbase = region + fr * 256;
+        const char* rbase = region + rrow * 256;
+        float* cptr = (float*)p.C + (long long)(mbase + rrow) * p.ldc + nbase + rk * 4;
+        const float* rptr = (const float*)p.res + (long long)(mbase + rrow) * p.ldres + nbase + rk * 4;
+        const long long cstep = 4ll * p.ldc, rstep = 4ll * p.ldres;
+        // ring depth: 8 loads (32 VGPRs) ahead - with the 128 accumulator registers, a pass of read-backs and the lane-held
+        // operands that is what fits without spilling; sched_barrier keeps the passes from being merged (the scheduler would
+        // otherwise hoist every pass's LDS traffic and spill ~300 registers)
+        constexpr int FR = RING < 8 ? RING : 8;
+        f32x4 ring[FR];
+        if (RES == 1) {
+#pragma unroll
+            for (int u = 0; u < FR; ++u) { ring[u] = *(const f32x4*)rptr; rptr += rstep; }
+        }
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+            for (int ii = 0; ii < ROWS / 16; ++ii) {
+                const int i = pass * (ROWS / 16) + ii;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *(f32x4*)(wbase + ii * 4096 + (((j * 4 + g) ^ fr) << 4)) = fops.lin(acc[i][j], i, j);
+            }
+            f32x4 val[QP];
+#pragma unroll
+            for (int q = 0; q < QP; ++q) {
+                const int r = q * 4 + rrow;                        // r & 15 = (4 q + rrow) & 15
+                val[q] = *(const f32x4*)(rbase + q * 1024 + ((rk ^ (r & 15)) << 4));
+            }
+#pragma unroll
+            for (int q = 0; q < QP; ++q) {
+                const int u = pass * QP + q;
+                if (RES == 1) {
+                    val[q] += ring[u % FR];
+                    if (u + FR < 32) { ring[u % FR] = *(const f32x4*)rptr; rptr += rstep; }
+                }
+                __builtin_nontemporal_store(val[q], (f32x4*)cptr);
+                cptr += cstep;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
     f32x4 rr[RING];
     auto load_res = [&](int u) {                           // unit u = rows 4u .. 4u+3 of the wave's sub-tile
         const int k = lane & 15;
         int m = mbase + u * 4 + (lane >> 4), n = nbase + k * 4;
         if (m > p.M - 1) m = p.M - 1;
         if (n > p.N - 4) n = p.N - 4;
+        if (diag_no_res) return (f32x4){0.f, 0.f, 0.f, 0.f};
         return *(const f32x4*)((const float*)p.res + p.rm(m) * p.ldres + n);
     };
     if (RES == 1) {
@@ -711,20 +870,23 @@ __device__ __forceinline__ void epi_staged32(const GemmArgs& p, f32x4 (&acc)[8][
             for (int j = 0; j < 4; ++j) {
                 const int chunk = (j * 4 + g) ^ (r & 15);
                 const int i = pass * (ROWS / 16) + ii;
-                *(f32x4*)(region + r * 256 + chunk * 16) = ops.lin(acc[i][j], i, j);
+                if (!diag_no_stage) *(f32x4*)(region + r * 256 + chunk * 16) = ops.lin(acc[i][j], i, j);
             }
         }
 #pragma unroll
         for (int q = 0; q < QP; ++q) {
             const int u = pass * QP + q;
             const int r = q * 4 + (lane >> 4), k = lane & 15;
-            f32x4 val = *(const f32x4*)(region + r * 256 + ((k ^ (r & 15)) << 4));
+            f32x4 val;
+            if (!diag_no_stage) val = *(const f32x4*)(region + r * 256 + ((k ^ (r & 15)) << 4));
+            else val = acc[pass & 7][q & 3];
             const int m = mbase + pass * ROWS + r, n = nbase + k * 4;
             if (RES == 1) {
                 val += rr[u % RING];
                 if (u + RING < 32) rr[u % RING] = load_res(u + RING);
             }
-            if (m < p.M && n < p.N) __builtin_nontemporal_store(val, (f32x4*)((float*)p.C + p.cm(m) * p.ldc + n));
+            if (diag_no_store) { asm volatile("" ::"v"(val)); }
+            else if (m < p.M && n < p.N) __builtin_nontemporal_store(val, (f32x4*)((float*)p.C + p.cm(m) * p.ldc + n));
             if (EMIT) {
                 float mean, m2;
                 slot_stats_row16(val, mean, m2);          // every lane takes part (rows beyond M: clamped duplicates)
@@ -1040,7 +1202,18 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
     const int chunk_len = cq + (xcd < cr ? 1 : 0);
     const int n_my = l < chunk_len ? (chunk_len - l + G8 - 1) / G8 : 0;
     if (n_my == 0) return;
-
+    // ---- start offsets (experiment switches, both off by default).  Workgroups that start together reach every tile seam
+    // together, and 256 CUs draining their C tiles at once share the chip's ~8 TB/s of fabric bandwidth (tools/store_bw.cpp:
+    // a CU alone stores a 128-KiB tile in 1.0 us, all 256 together in 3.6-4.4 us; the fp32 read-modify-write tiles move
+    // 512 KiB each and their drain runs at the HBM rate).  The tile period is the same for every CU, so a start offset would
+    // persist.  Measured (tools/bench_gemm_epi.py, TDC_GEMM_STAGGER_NS / TDC_GEMM_STAGGER_XCD_NS): offsetting the four
+    // tile-column groups of an XCD shortens the drain but costs the main loop as much (the groups stop sharing operand
+    // panels in flight in L2): no net gain at 1-8 us.
+    if (p.stagger_ticks > 0 || p.stagger_xcd_ticks > 0) {
+        const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)((l >> 3) & 3) * p.stagger_ticks +
+                                         (unsigned long long)xcd * p.stagger_xcd_ticks;
+        while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
+    }
     // ---- staging cursor: SGPR bases + per-lane byte offsets of the tile being staged
     unsigned a_so[2][2], w_so[2][2];
     const char* a_base;
@@ -1196,9 +1369,14 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
     pa1 = a_base + 128; pa2 = a_base + 256; pw2 = w_base + 256;
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     T2_BARRIER();
-    if (wave >= 4) T2_BARRIER();      // stagger (see gemm256_kernel)
-
     for (int it = 0; it < n_my; ++it) {
+        // stagger (see gemm256_kernel), re-established for every tile: the two wave groups leave a tile's loop one barrier apart,
+        // and a group's epilogue holds no barrier - left staggered, waves 4-7 would sit at their last barrier of the tile for the
+        // whole length of waves 0-3's epilogue and waves 0-3 then at their first barrier of the next tile for the whole length of
+        // waves 4-7's: the two halves of the C tile drained one after the other (per-wave stamps, tools/run_gemm_epi_parts.sh:
+        // first epilogue start -> last store acknowledged = twice a wave's epilogue).  Closing the stagger behind the loop
+        // (below) and opening it again here costs one barrier wait per tile and lets all eight epilogues run together.
+        if (wave >= 4) T2_BARRIER();
         const bool more = it + 1 < n_my;
         int m1 = 0, n1 = 0;
         if (more) {
@@ -1228,6 +1406,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
             else tile_loop(std::false_type(), std::false_type(), m1, n1);
         }
         par ^= nk & 1;
+        if (wave < 4) T2_BARRIER();   // matches the stagger barrier of waves 4-7: both groups enter the epilogue together
 #ifdef TDC_GEMM_DIAG
         if (p.stamps && threadIdx.x == 0) {
             __builtin_amdgcn_sched_barrier(0);
@@ -1241,6 +1420,13 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
         // next tile's staged loads in the in-order vmcnt queue).
         int elane = lane;
         asm volatile("" : "+v"(elane));
+#ifdef TDC_GEMM_DIAG
+        if (p.wstamps && lane == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            p.wstamps[((size_t)id * 8 + wave) * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
         const EpiLane el = *el_park;
         EpiLane el_next = el;
         if (more) el_next = load_epi_lane(m1, n1);                       // complete by the vmcnt(0) below
@@ -1265,15 +1451,28 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
             __builtin_amdgcn_sched_barrier(0);
         }
 #endif
+#ifdef TDC_GEMM_DIAG
+        if (p.wstamps && lane == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            p.wstamps[((size_t)id * 8 + wave) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
         // A compiler-visible vmcnt(0): without it the waitcnt pass protects the fragment registers of the next main loop
         // against this epilogue's (long finished) loads with a vmcnt(0) INSIDE the K loop, which would drain the staging
         // pipeline every iteration.  Here it only waits for the acknowledgement of the last stores.  Unconditional: the
         // pass cannot tell that !more leaves the loop.
         __builtin_amdgcn_s_waitcnt(0x0F70);
+#ifdef TDC_GEMM_DIAG
+        if (p.wstamps && lane == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            p.wstamps[((size_t)id * 8 + wave) * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
         *el_park = el_next;
         id += G8; m0 = m1; n0 = n1;
     }
-    if (wave < 4) T2_BARRIER();   // matches the stagger barrier of waves 4-7
 }
 #undef T2_END_LOADS
 #undef T2_BARRIER
@@ -1316,6 +1515,7 @@ inline bool use_256(int M, int N, int K) {
 #ifdef TDC_GEMM_DIAG
 }
 unsigned long long* tdc_gemm_diag_stamps = nullptr;   // set by tools/gemm_stamps.cpp
+unsigned long long* tdc_gemm_diag_wstamps = nullptr;
 namespace {
 #endif
 template <class T, bool FP8>
@@ -1330,11 +1530,14 @@ int launch(const tdc_gemm_desc* d, hipStream_t st) {
     a.out_fp8 = d->out_fp8; a.out_stats = d->out_stats; a.out_w2max = d->out_w2max; a.out_bmax = d->out_bmax;
     a.out_wscale = d->out_wscale;
     a.debug = tdc_gemm_debug_mode;
+    a.stagger_ticks = 0;
+    a.stagger_xcd_ticks = 0;
 #ifdef TDC_GEMM_DIAG
     { const char* e = getenv("TDC_GEMM_DIAGMODE"); a.diag_mode = e ? atoi(e) : 0; }
 #endif
 #ifdef TDC_GEMM_DIAG
     a.stamps = tdc_gemm_diag_stamps;
+    a.wstamps = tdc_gemm_diag_wstamps;
 #endif
     a.am = {d->a_map.seg, d->a_map.stride, d->a_map.off, d->a_map.inner};
     a.cm = {d->c_map.seg, d->c_map.stride, d->c_map.off, d->c_map.inner};
@@ -1367,6 +1570,14 @@ int launch(const tdc_gemm_desc* d, hipStream_t st) {
                 HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm256p_kernel<T, true, FP8>,
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, T2P_LDS));
                 attr256p = true;
+            }
+            {   // start-offset experiments (see the kernel): off unless the environment asks
+                static int st_env = -2, stx_env = -2;
+                if (st_env == -2) { const char* e = getenv("TDC_GEMM_STAGGER_NS"); st_env = e ? atoi(e) : 0; }
+                if (stx_env == -2) { const char* e = getenv("TDC_GEMM_STAGGER_XCD_NS"); stx_env = e ? atoi(e) : 0; }
+                const int tiles_per_cu = (a.tiles_m * a.tiles_n) / G;
+                a.stagger_ticks = tiles_per_cu >= 8 ? st_env / 10 : 0;
+                a.stagger_xcd_ticks = tiles_per_cu >= 8 ? stx_env / 10 : 0;
             }
             if (d->ln_stats) hipLaunchKernelGGL((gemm256p_kernel<T, true, FP8>), dim3(G), dim3(512), T2P_LDS, st, a);
             else hipLaunchKernelGGL((gemm256p_kernel<T, false, FP8>), dim3(G), dim3(512), T2P_LDS, st, a);

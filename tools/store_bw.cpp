@@ -24,11 +24,19 @@ __device__ __forceinline__ void st16(u32x4* p, u32x4 v) {
     else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
 
+// spacer: every wave runs `spacer` x 64 MFMAs (~ spacer x 0.5 us) before each tile's drain (the "main loop" between two
+// drains); stagger_ns: workgroup l of its XCD (blockIdx.x >> 3) starts (l >> 3) * stagger_ns late (tile-column groups of the
+// GEMM's 8 x 4 patch per XCD); one_xcd >= 0: only workgroups running on that XCC_ID take part.
 template <int MODE, bool MFMA>
 __global__ __launch_bounds__(512, 2) void k(unsigned short* C, long long ldc, int tiles, int tiles_n, unsigned long long* stamps,
-                                            float* sink) {
+                                            float* sink, int spacer, int stagger_ns, int one_xcd) {
     extern __shared__ char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (one_xcd >= 0 && (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7) != one_xcd) return;
+    if (stagger_ns > 0) {
+        const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)((blockIdx.x >> 3) >> 3) * stagger_ns / 10;
+        while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(4);
+    }
     u32x4 v = {threadIdx.x, blockIdx.x, 0x3f803f80u, 0x40004000u};
     f32x4 acc[8];
     bf16x8 a, b;
@@ -38,6 +46,10 @@ __global__ __launch_bounds__(512, 2) void k(unsigned short* C, long long ldc, in
         const int id = blockIdx.x + gridDim.x * t;
         const int tm = id / tiles_n, tn = id % tiles_n;
         unsigned short* tile = C + (long long)tm * 256 * ldc + tn * 256;
+        for (int it = 0; it < spacer * 8; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+        }
         __syncthreads();
         unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         if (!MFMA || wave < 4) {
@@ -69,7 +81,7 @@ __global__ __launch_bounds__(512, 2) void k(unsigned short* C, long long ldc, in
             if (wave == 0) stamps[((size_t)blockIdx.x * tiles + t) * 16 + 1] = t2 - t0;
         }
     }
-    if (MFMA) {
+    {
         float s = 0.f;
         for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][3];
         if (s == 123.456f) sink[0] = s;
@@ -79,6 +91,7 @@ __global__ __launch_bounds__(512, 2) void k(unsigned short* C, long long ldc, in
 int main(int argc, char** argv) {
     int G = argc > 1 ? atoi(argv[1]) : 256, tiles = argc > 2 ? atoi(argv[2]) : 8, mode = argc > 3 ? atoi(argv[3]) : 0;
     int mfma = argc > 4 ? atoi(argv[4]) : 0;
+    int spacer = argc > 5 ? atoi(argv[5]) : 0, stagger_ns = argc > 6 ? atoi(argv[6]) : 0, one_xcd = argc > 7 ? atoi(argv[7]) : -1;
     const int N = 3456, tiles_n = 13;                      // 13 whole column tiles of the SigLIP qkv output
     const long long ldc = N;
     const int tiles_m = (G * tiles + tiles_n - 1) / tiles_n + 1;
@@ -90,7 +103,7 @@ int main(int argc, char** argv) {
     auto run = [&](auto kern) -> int {
         CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         for (int rep = 0; rep < 3; ++rep) {
-            hipLaunchKernelGGL(kern, dim3(G), dim3(512), 160 * 1024, 0, C, ldc, tiles, tiles_n, st, sink);
+            hipLaunchKernelGGL(kern, dim3(G), dim3(512), 160 * 1024, 0, C, ldc, tiles, tiles_n, st, sink, spacer, stagger_ns, one_xcd);
             CK(hipDeviceSynchronize());
         }
         return 0;
@@ -105,11 +118,14 @@ int main(int argc, char** argv) {
     for (int b = 0; b < G; ++b)
         for (int t = 1; t < tiles; ++t) {          // skip the first tile (cold)
             const unsigned long long* s = &h[((size_t)b * tiles + t) * 16];
+            if (s[1] == 0) continue;               // workgroup did not take part (one_xcd)
             wg.push_back((double)s[1] * 0.01);     // us (100 MHz)
             for (int w = 0; w < (mfma ? 4 : 8); ++w) wv.push_back((double)s[w * 2] * 0.01);
         }
     std::sort(wg.begin(), wg.end()); std::sort(wv.begin(), wv.end());
+    if (wg.empty()) { printf("no workgroup took part\n"); return 0; }
     const double med = wg[wg.size() / 2];
+    printf("spacer=%d stagger=%dns one_xcd=%d n=%zu | ", spacer, stagger_ns, one_xcd, wg.size());
     printf("G=%3d mode=%d mfma=%d  tile drain (workgroup, barrier to barrier): median %.2f us  min %.2f  max %.2f | per storing wave "
            "median %.2f us | %.1f GB/s per CU, %.2f TB/s over %d CUs\n", G, mode, mfma, med, wg.front(), wg.back(), wv[wv.size() / 2],
            131072.0 / med * 1e-3, 131072.0 / med * 1e-6 * G, G);
