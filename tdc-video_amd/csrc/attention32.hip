@@ -208,18 +208,22 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(AttnArgs p) {
             const float m_new = fmaxf(m_run[qb], mx * c);
             const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
             m_run[qb] = m_new;
-            float rs = 0.f;
+            // exponent arguments and row sums on register pairs (v_pk_fma_f32 / v_pk_add_f32: one issue slot per two values)
+            const f32x2_t c2 = {c, c}, nm2 = {-m_new, -m_new};
+            f32x2_t rs2 = {0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int st = 0; st < 2; ++st)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][kb][st * 8 + j], c, -m_new));
-                        rs += e;
-                        pf[qb][kb][st][j] = (T)e;
+                    for (int j = 0; j < 8; j += 2) {
+                        const f32x2_t z = __builtin_elementwise_fma((f32x2_t){s[qb][kb][st * 8 + j], s[qb][kb][st * 8 + j + 1]}, c2, nm2);
+                        const f32x2_t e = {__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])};
+                        rs2 += e;
+                        pf[qb][kb][st][j] = (T)e[0];
+                        pf[qb][kb][st][j + 1] = (T)e[1];
                     }
-            l_run[qb] = l_run[qb] * alpha + rs;
+            l_run[qb] = l_run[qb] * alpha + (rs2[0] + rs2[1]);
             // the running max only moves in the first few tiles: skip the O rescale when no lane's max changed
             if (!__all(alpha == 1.0f)) {
 #pragma unroll

@@ -578,7 +578,7 @@ __device__ __forceinline__ void epi_staged16(const GemmArgs& p, f32x4 (&acc)[8][
             for (int q = 0; q < ROWS / 8; ++q) val[q] = *(const v8*)(rbase + q * 1024);
 #pragma unroll
             for (int q = 0; q < ROWS / 8; ++q) {
-                __builtin_nontemporal_store(val[q], (v8*)cptr);
+                __builtin_nontemporal_store(val[q], (v8*)cptr);      // plain (cached) stores measure the same
                 cptr += step;
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -672,7 +672,7 @@ __device__ __forceinline__ void epi_staged_swiglu(const GemmArgs& p, f32x4 (&acc
             for (int q = 0; q < ROWS / 16; ++q) val[q] = *(const v8*)(rbase + q * 1024);
 #pragma unroll
             for (int q = 0; q < ROWS / 16; ++q) {
-                __builtin_nontemporal_store(val[q], (v8*)cptr);
+                __builtin_nontemporal_store(val[q], (v8*)cptr);      // plain (cached) stores measure the same
                 cptr += step;
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -798,7 +798,7 @@ __device__ __forceinline__ void epi_staged32(const GemmArgs& p, f32x4 (&acc)[8][
     constexpr int NPASS = 128 / ROWS, QP = ROWS / 4;      // QP read-back instructions (4 rows x 256 B each) per pass
     // The residual loads run as a ring of RING loads ahead of the read-back, independent of the staging passes (they
     // touch no LDS); they come from clamped (always valid) addresses so that no branch - and no vmcnt(0) - separates them.
-    if (TDC_FAST32 && !EMIT && !diag_no_store && !diag_no_stage && !diag_no_res && p.cm.seg == 0 && (RES == 0 || p.rm.seg == 0) &&
+    if (TDC_FAST32 && !diag_no_store && !diag_no_stage && !diag_no_res && p.cm.seg == 0 && (RES == 0 || p.rm.seg == 0) &&
         mbase + 128 <= p.M && nbase + 64 <= p.N) {
         // interior sub-tile, identity row maps (see epi_staged16): running pointers for the residual loads and the stores, the
         // residual ring filled up front, a pass = 4 writes, 4 read-backs, 4 stores of straight-line code
@@ -809,6 +809,10 @@ __device__ __forceinline__ void epi_staged32(const GemmArgs& p, f32x4 (&acc)[8][
         float* cptr = (float*)p.C + (long long)(mbase + rrow) * p.ldc + nbase + rk * 4;
         const float* rptr = (const float*)p.res + (long long)(mbase + rrow) * p.ldres + nbase + rk * 4;
         const long long cstep = 4ll * p.ldc, rstep = 4ll * p.ldres;
+        // EMIT (LayerNorm fusion, producer side): the 16-bit row copy and the per-slot (mean, M2) partials of the same rows
+        T* xptr = EMIT ? (T*)p.x16 + (long long)(mbase + rrow) * p.ldx16 + nbase + rk * 4 : nullptr;
+        float* lptr = EMIT ? p.ln_part + 2 * ((long long)(nbase >> 6) * p.M + mbase + rrow) : nullptr;
+        const long long xstep = 4ll * p.ldx16;
         // ring depth: 8 loads (32 VGPRs) ahead - with the 128 accumulator registers, a pass of read-backs and the lane-held
         // operands that is what fits without spilling; sched_barrier keeps the passes from being merged (the scheduler would
         // otherwise hoist every pass's LDS traffic and spill ~300 registers)
@@ -842,6 +846,17 @@ __device__ __forceinline__ void epi_staged32(const GemmArgs& p, f32x4 (&acc)[8][
                 }
                 __builtin_nontemporal_store(val[q], (f32x4*)cptr);
                 cptr += cstep;
+                if (EMIT) {
+                    float mean, m2;
+                    slot_stats_row16(val[q], mean, m2);
+                    v4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (T)val[q][e];
+                    *(v4*)xptr = o;
+                    xptr += xstep;
+                    if (rk == 0) *(float2*)lptr = make_float2(mean, m2);
+                    lptr += 8;
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -111,13 +111,45 @@ __global__ void cossim_final(const float* part, int Tn, float* sims) {
 }
 
 // ------------------------------------------------------------------------------------------------ pooling
+// one workgroup per frame; thread = (16-byte column chunk, token phase): 16-byte loads, several independent rows in flight
+// per thread, the token phases of a chunk combined through LDS in a fixed order (deterministic).  The previous form - one
+// thread per column walking all P tokens with 2-byte loads - was a 576-deep dependent load chain: 0.9 ms whatever the frame
+// count (rocprof at T = 64).
 template <class T>
 __global__ __launch_bounds__(256) void token_mean_kernel(const T* x, int P, int ld, T* y) {
+    typedef typename VecOf<T>::v8 v8;
+    __shared__ float part[256][8];
     const int b = blockIdx.x;
-    for (int c = threadIdx.x; c < ld; c += 256) {
-        float s = 0.f;
-        for (int t = 0; t < P; ++t) s += (float)x[((long long)b * P + t) * ld + c];
-        y[(long long)b * ld + c] = (T)(s / (float)P);
+    const int nch = ld >> 3;                                   // 16-byte chunks per row (ld % 8 == 0: host-checked)
+    const int nchb = nch < 256 ? nch : 256;                    // chunks handled per sweep
+    const int phases = 256 / nchb;                             // token phases (1 when a row has >= 256 chunks)
+    const int c0 = threadIdx.x % nchb, ph = threadIdx.x / nchb;
+    const T* base = x + (long long)b * P * ld;
+    for (int cb = 0; cb < nch; cb += nchb) {                   // uniform trip count: barriers inside
+        const int c = cb + c0;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (ph < phases && c < nch) {
+#pragma unroll 4
+            for (int t = ph; t < P; t += phases) {
+                const v8 v = *(const v8*)(base + (long long)t * ld + c * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[threadIdx.x][e] = acc[e];
+        __syncthreads();
+        if (ph == 0 && c < nch) {
+            v8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float s = part[c0][e];
+                for (int q = 1; q < phases; ++q) s += part[q * nchb + c0][e];
+                o[e] = (T)(s / (float)P);
+            }
+            *(v8*)(y + (long long)b * ld + c * 8) = o;
+        }
+        __syncthreads();
     }
 }
 template <class T>
@@ -275,7 +307,7 @@ extern "C" int tdc_frame_cossim(const void* f, long long n, int T, float* sims, 
 extern "C" size_t tdc_frame_cossim_scratch_floats(int T) { return (size_t)T * CS_CHUNKS * 2; }
 
 extern "C" int tdc_token_mean(const void* x, int P, int ld, void* y, int B, int dtype, void* stream) {
-    if (!x || !y || B <= 0 || P <= 0) return TDC_E_BADARG;
+    if (!x || !y || B <= 0 || P <= 0 || ld <= 0 || (ld & 7) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return TDC_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     DISPATCH(dtype, hipLaunchKernelGGL(token_mean_kernel<TT>, dim3(B), dim3(256), 0, st, (const TT*)x, P, ld, (TT*)y));
     return (int)hipGetLastError();

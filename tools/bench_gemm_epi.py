@@ -1,5 +1,6 @@
 """Per tower-GEMM type (real epilogue: fp32 residual RMW / GELU / SwiGLU / plain 16-bit): time of the whole kernel vs the
-same launch with the epilogue skipped (tdc_gemm_set_debug(1)), i.e. the share of the C-tile drain.  bf16, one MI355X."""
+same launch with the epilogue skipped (tdc_gemm_set_debug(1)), i.e. the share of the C-tile drain.  bf16, one MI355X.
+With a second argument N: also the same launch under tdc_gemm_set_debug(N) (A/B of an epilogue experiment switch)."""
 import math
 import os
 import sys
@@ -14,6 +15,7 @@ from tools.bench_ops import timeit  # noqa: E402
 
 def main():
     frames = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    alt = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     dtype = torch.bfloat16
     g = torch.Generator(device="cuda").manual_seed(0)
     Ms, Md = frames * 729, frames * 730
@@ -41,18 +43,22 @@ def main():
             fn = lambda: ops.gemm(a, w, bias=bias, act=act, out=out)
         L.load().tdc_gemm_set_debug(0)
         timeit(fn, iters=10)          # the first timed batch on fresh buffers runs 10-13 % slow (first touch): discard it
-        ms = ms0 = 1e9
-        for _ in range(2):            # alternate the two forms, keep the better of two batches each
+        ms = ms0 = msa = 1e9
+        for _ in range(2):            # alternate the forms, keep the better of two batches each
             L.load().tdc_gemm_set_debug(0)
             ms = min(ms, timeit(fn, iters=10))
             L.load().tdc_gemm_set_debug(1)
             ms0 = min(ms0, timeit(fn, iters=10))
+            if alt:
+                L.load().tdc_gemm_set_debug(alt)
+                msa = min(msa, timeit(fn, iters=10))
         L.load().tdc_gemm_set_debug(0)
         fl = 2.0 * M * N * K
         layers = 27 if name.startswith("siglip") else 40
         tot[0] += ms * layers; tot[1] += ms0 * layers
-        print("%-11s M=%6d N=%5d K=%5d  %7.3f ms %7.1f TF/s | no-epilogue %7.3f ms %7.1f TF/s | epilogue %4.1f %%"
-              % (name, M, N, K, ms, fl / ms / 1e9, ms0, fl / ms0 / 1e9, 100 * (ms - ms0) / ms), flush=True)
+        print("%-11s M=%6d N=%5d K=%5d  %7.3f ms %7.1f TF/s | no-epilogue %7.3f ms %7.1f TF/s | epilogue %4.1f %%%s"
+              % (name, M, N, K, ms, fl / ms / 1e9, ms0, fl / ms0 / 1e9, 100 * (ms - ms0) / ms,
+                 " | debug %d: %7.3f ms" % (alt, msa) if alt else ""), flush=True)
         del a, w
     print("towers (x layers): %.1f ms, without epilogues %.1f ms" % (tot[0], tot[1]))
 

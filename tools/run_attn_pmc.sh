@@ -17,8 +17,8 @@ res = collections.defaultdict(dict)
 for f in sorted(glob.glob(out + "/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
         k = r.get("Kernel_Name", "")
-        if "attn_kernel" not in k: continue
-        key = "d96" if "Li96E" in k else "d64"
+        if "attn_kernel" not in k and "attn32_kernel" not in k: continue
+        key = ("32x32 " if "attn32" in k else "16x16 ") + ("d72" if ("Li96E" in k or "Li80E" in k) else "d64")
         res[key].setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 with open(out + "/summary.txt", "w") as fo:
     for key, d in res.items():
