@@ -7,7 +7,8 @@ A "step" = one pass of the hot path (S0-S10 of SURVEY.md 3.2: DINOv2-g + SigLIP-
 segmentation, aux projectors, SVA 576->144, mm_projector, unpad/newline, batched Q-Former TDC compressor,
 vision_proj + L2, token emission) over ONE synthetic video of T frames whose pixels are already resident in HBM.
 For N>1 the T frames of the one video are sharded by contiguous ranges over the ranks (strong scaling), with the RCCL
-exchanges of tdc-video_amd/dist.py (similarities all-gather, key-frame query hand-off, emitted-token all-gather).
+exchanges of tdc-video_amd/dist.py (boundary-frame DINOv2 features, similarities all-gather, key-frame query hand-off,
+emitted-token all-gather).
 Prints ONE JSON line on rank 0 (contract in the task statement) incl. `roofline` (dominant kernel = tdc_gemm MFMA
 kernel, timed live with events on the launch stream) and `cpu_baseline` (the oracle on the host cores, bounded sample).
 """
@@ -251,9 +252,8 @@ def main():
                                     frame_cap=T, audio={"audio_wav": wav} if wav is not None else None)
     else:
         from tdc_video_amd import dist as tdist
-        halo = 1 if rank < world - 1 else 0
-        vs = synth_video(lo, hi, px_s, dev, dtype)
-        vd = synth_video(lo, hi + halo, px_d, dev, dtype, seed=4321 if px_d != px_s else 1234)
+        vs = synth_video(lo, hi, px_s, dev, dtype)       # a rank only ever holds its own frames
+        vd = synth_video(lo, hi, px_d, dev, dtype, seed=4321 if px_d != px_s else 1234)
         sharded = tdist.ShardedVideoEncoder(enc, rank, world)
 
         def step():

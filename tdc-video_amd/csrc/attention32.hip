@@ -157,8 +157,12 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(AttnArgs p) {
     const int ntiles = (p.sk + KT32 - 1) / KT32;
     const float c = p.scale_log2;
 
-    auto do_tile = [&](const int tile, auto partial_c) {
+    // NQ = query blocks of this wave that hold at least one row < sq (the first NQ ones), NKB = key blocks of the tile that hold
+    // at least one key < sk: S = 729 / 730 / 577 leave 32-row blocks past the end of the sequence on both sides (the last
+    // workgroup of a head, the last tile of the keys), whose MFMAs and softmax are skipped whole
+    auto do_tile = [&](const int tile, auto partial_c, auto nq_c, auto nkb_c) {
         constexpr bool PARTIAL = decltype(partial_c)::value;
+        constexpr int NQ = decltype(nq_c)::value, NKB = decltype(nkb_c)::value;
         const int buf = tile & 1;
         const T* kt_ = Ks + buf * (KT32 * KROW);
         const T* vt_ = Vs + buf * (KT32 * VROW);
@@ -173,28 +177,28 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(AttnArgs p) {
         // ---- S^T = K Q^T: s[qb][kb] holds, for query r, keys kv0 + 32 kb + (e & 3) + 8 (e >> 2) + 4 hh
         f32x16 s[QB][2];
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb)
+        for (int qb = 0; qb < NQ; ++qb)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) s[qb][kb][e] = 0.f;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < NKB; ++kb) {
             const int key = kb * 32 + r;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const v8 kf = *(const v8*)(kt_ + key * KROW + (kswz(key, ks * 2 + hh) << 3));
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb) s[qb][kb] = mfma32(kf, qf[qb][ks], s[qb][kb]);
+                for (int qb = 0; qb < NQ; ++qb) s[qb][kb] = mfma32(kf, qf[qb][ks], s[qb][kb]);
             }
         }
         // ---- online softmax in base 2 on the raw scores; P^T fragments in place
         v8 pf[QB][2][2];
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
+        for (int qb = 0; qb < NQ; ++qb) {
             if (PARTIAL) {
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
                         if (kv0 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh >= p.sk) s[qb][kb][e] = -INFINITY;
@@ -202,8 +206,10 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(AttnArgs p) {
             float mx = fmaxf(s[qb][0][0], s[qb][0][1]);
 #pragma unroll
             for (int e = 2; e < 16; e += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[qb][0][e]), s[qb][0][e + 1]);
+            if (NKB == 2) {
 #pragma unroll
-            for (int e = 0; e < 16; e += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[qb][1][e]), s[qb][1][e + 1]);
+                for (int e = 0; e < 16; e += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[qb][1][e]), s[qb][1][e + 1]);
+            }
             mx = fmaxf(mx, other_half(mx));
             const float m_new = fmaxf(m_run[qb], mx * c);
             const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(AttnArgs p) {
             const f32x2_t c2 = {c, c}, nm2 = {-m_new, -m_new};
             f32x2_t rs2 = {0.f, 0.f};
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                 for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -236,8 +242,9 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(AttnArgs p) {
         //      32 kb + 16 st + 4 hh (+ 8), columns 32 db + 16 (r >> 4): lane 4 q + pp supplies row q, columns 4 pp ..
 #pragma unroll
         for (int db = 0; db < NDB; ++db) {
+            if (NQ == 0) break;
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                 for (int st = 0; st < 2; ++st) {
                     const int li = r & 15, qq = li >> 2, pp = li & 3;
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(AttnArgs p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
 #pragma unroll
-                    for (int qb = 0; qb < QB; ++qb) o_acc[qb][db] = mfma32(vf, pf[qb][kb][st], o_acc[qb][db]);
+                    for (int qb = 0; qb < NQ; ++qb) o_acc[qb][db] = mfma32(vf, pf[qb][kb][st], o_acc[qb][db]);
                 }
         }
         __syncthreads();    // tile t+1 is visible; everyone is done reading tile t
@@ -262,8 +269,19 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(AttnArgs p) {
     write_lds(0);
     if (ntiles > 1) issue_loads(KT32);
     __syncthreads();
-    for (int tile = 0; tile < ntiles - 1; ++tile) do_tile(tile, std::false_type());
-    do_tile(ntiles - 1, std::true_type());
+    int nq = (p.sq - q0 + 31) >> 5;                              // wave-uniform
+    nq = nq < 0 ? 0 : (nq > QB ? QB : nq);
+    const bool last_two = p.sk - (ntiles - 1) * KT32 > 32;       // the last tile's second key block holds valid keys
+    auto run = [&](auto nq_c) {
+        typedef std::integral_constant<int, 2> two;
+        typedef std::integral_constant<int, 1> one;
+        for (int tile = 0; tile < ntiles - 1; ++tile) do_tile(tile, std::false_type(), nq_c, two());
+        if (last_two) do_tile(ntiles - 1, std::true_type(), nq_c, two());
+        else do_tile(ntiles - 1, std::true_type(), nq_c, one());
+    };
+    if (nq >= QB) run(std::integral_constant<int, QB>());
+    else if (QB > 1 && nq == 1) run(std::integral_constant<int, 1>());
+    else run(std::integral_constant<int, 0>());
 
     // ---- finalise: lane (r, hh) holds O[q = q0 + 32 qb + r][32 db + 8 (e >> 2) + 4 hh + (e & 3)]
 #pragma unroll

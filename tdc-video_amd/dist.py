@@ -4,9 +4,12 @@ torch.distributed (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU te
 Rank r owns the contiguous frames [lo, hi) of the frames that survive the a1 cap.  Cross-rank data flow per video:
   0. a1 (frame budget + uniform sub-sampling) is host integer logic on (T0, text length): every rank computes the same
      selection (`frame_plan`) and loads / is handed only its own frames.
-  1. DINO on the local frames plus a one-frame halo (the next rank's first frame is re-encoded locally: 1/(T/P) extra
-     tower work instead of a 1.7 MB send that would serialise the ranks) -> local adjacent similarities;
-     all-gather of the T-1 fp32 similarities -> every rank runs the identical stable selection -> identical plan.
+  1. DINO on the local frames; every rank but the first sends the feature rows of its FIRST frame (576 x 1536 16-bit values,
+     1.77 MB) to its left neighbour, which needs them for its last adjacent similarity (round 1 re-encoded that frame on
+     both ranks: one frame in 65 sounds cheap, but it pushes the DINOv2 qkv / fc1 GEMMs of a 64-frame shard over a tile-round
+     boundary of the persistent kernel - ~2 % of the step against ~0.1 ms of xGMI transfer); callers that still pass the
+     halo frame's pixels get the old behaviour.  All-gather of the T-1 fp32 similarities -> every rank runs the identical
+     stable selection -> identical plan.
   2. SigLIP + connector on the local frames (no communication).  Audio (a20): a rank runs BEATs on the 10-second windows
      its own seconds fall into (a window that straddles a rank boundary is encoded by both ranks, like the DINO halo)
      and builds the audio tokens of its own frames; no exchange.
@@ -60,13 +63,24 @@ def split_plan(plan, ranges, Nf, K):
 
 
 class TorchComm:
-    """torch.distributed transport (RCCL on the GPUs of a node; gloo in the CPU tests)."""
+    """torch.distributed transport (RCCL on the GPUs of a node; gloo in the CPU tests and in the one-GPU rehearsals).
+    RCCL operations are ordered on the stream; gloo's point-to-point operations read a device tensor from the host through
+    its raw pointer with no stream ordering at all, so with gloo the device is synchronised before anything is posted."""
 
     def __init__(self, rank, world, group=None):
         self.rank, self.world, self.group = rank, world, group
+        self._host_side = None
+
+    def _sync_if_host_side(self, t):
+        if self._host_side is None:
+            import torch.distributed as dist
+            self._host_side = dist.get_backend(self.group) != "nccl"
+        if self._host_side and t is not None and t.is_cuda:
+            torch.cuda.synchronize(t.device)
 
     def all_gather(self, t):
         import torch.distributed as dist
+        self._sync_if_host_side(t)
         out = [torch.empty_like(t) for _ in range(self.world)]
         dist.all_gather(out, t, group=self.group)
         return out
@@ -77,8 +91,10 @@ class TorchComm:
         ops_ = [dist.P2POp(dist.isend, t, dst, self.group) for t, dst in sends] + \
                [dist.P2POp(dist.irecv, buf, src, self.group) for buf, src in recvs]
         if ops_:
+            self._sync_if_host_side((sends + recvs)[0][0])
             for rq in dist.batch_isend_irecv(ops_):
                 rq.wait()
+            self._sync_if_host_side((sends + recvs)[0][0])
 
 
 class ShardedVideoEncoder:
@@ -87,16 +103,18 @@ class ShardedVideoEncoder:
         self.comm = comm if comm is not None else TorchComm(rank, world, group)
 
     # ---- a1 on every rank --------------------------------------------------------------------------------------------
-    def frame_plan(self, T0, budget_text_len, frame_cap=224, video_index=None):
+    def frame_plan(self, T0, budget_text_len, frame_cap=224, video_index=None, halo=False):
         """tdc/cambrian_arch.py:899-935 for a T0-frame video: which input frames survive the budget, which of them this rank
-        encodes (`siglip_frames`; `dino_frames` = the same plus the one-frame halo), and the per-second 0/1 vector the audio
-        interleave needs.  Pure host integers: identical on every rank."""
+        encodes (`siglip_frames`; `dino_frames` = the same - plus the next rank's first frame with halo=True, the
+        re-encode-instead-of-exchange variant), and the per-second 0/1 vector the audio interleave needs.  Pure host
+        integers: identical on every rank."""
         cfg = self.e.cfg
         idx = seg.uniform_indices(T0, min(seg.get_max_num_frames(budget_text_len, cfg), frame_cap))
         T = len(idx)
         lo, hi = seg.shard_ranges(T, self.world)[self.rank]
-        halo = 1 if lo < hi < T else 0               # a rank without frames (T < world) has no halo either
-        return dict(idx=idx, T=T, lo=lo, hi=hi, siglip_frames=idx[lo:hi], dino_frames=idx[lo:hi + halo],
+        want_halo = bool(halo)
+        halo = 1 if (halo and lo < hi < T) else 0    # a rank without frames (T < world) has no halo either
+        return dict(idx=idx, T=T, lo=lo, hi=hi, siglip_frames=idx[lo:hi], dino_frames=idx[lo:hi + halo], recompute_halo=want_halo,
                     sample_indices=sample_indicator(T0, idx, video_index))
 
     def _tokens_per_frame(self, image_size, audio):
@@ -118,9 +136,10 @@ class ShardedVideoEncoder:
         return torch.cat([o[:c] for o, c in zip(out, counts)], 0)
 
     def encode_video(self, px_siglip_local, px_dino_local_halo, T, image_size, n_text_tokens, prompt_ids, audio=None,
-                     sample_indices=None):
-        """px_siglip_local: frames [lo,hi) of the T frames that survive a1 (frame_plan); px_dino_local_halo: frames
-        [lo, hi + 1) (no halo on the last rank).  audio: as in the serial path - a full [T, 50, 768] token tensor, or a dict
+                     sample_indices=None, recompute_halo=False):
+        """px_siglip_local: frames [lo,hi) of the T frames that survive a1 (frame_plan); px_dino_local_halo: the same frames for
+        the DINOv2 tower (the boundary frame's features are then exchanged), or frames [lo, hi + 1) - the next rank's first
+        frame appended (none on the last rank) - with recompute_halo=True (on EVERY rank), to re-encode that frame here instead.  audio: as in the serial path - a full [T, 50, 768] token tensor, or a dict
         with "audio_tokens" / "beats_windows" (all windows) / "audio_wav" (raw 16 kHz waveform: BEATs runs here, on this
         rank's windows only); sample_indices: frame_plan's per-second vector (all ones when a1 did not cap)."""
         e, rank, world = self.e, self.rank, self.world
@@ -130,7 +149,7 @@ class ShardedVideoEncoder:
         cfg = e.cfg
         # 1. DINO (+halo) -> similarities -> identical segmentation everywhere
         n_d = px_dino_local_halo.shape[0]
-        assert n_d == Tl + (1 if lo < hi < T else 0) and px_siglip_local.shape[0] == Tl
+        assert n_d == Tl + (1 if (recompute_halo and lo < hi < T) else 0) and px_siglip_local.shape[0] == Tl
         if Tl == 0:
             # more ranks than frames (T < world <= 8 < max_num_segments + 1: the pass-through case, no similarities, no
             # Q-Former): this rank only takes part in the final all-gather
@@ -150,10 +169,21 @@ class ShardedVideoEncoder:
         if T <= mns + 1:
             seg_idx = list(range(T))
         else:
-            if n_d >= 2:
-                sims_local = e.sims_tensor(dino_all, n_d)
-            else:
-                sims_local = torch.zeros(0, dtype=torch.float32, device=dino_all.device)
+            # T > 25 >= 3 * world: every rank owns frames.  Local pairs, then the pair across the right-hand boundary.
+            sims_parts = []
+            if not recompute_halo:
+                first = dino_all[:P].contiguous()
+                halo_rows = torch.empty_like(first) if rank < world - 1 else None
+                self.comm.exchange([(first, rank - 1)] if rank > 0 else [],
+                                   [(halo_rows, rank + 1)] if rank < world - 1 else [])
+                if Tl >= 2:
+                    sims_parts.append(e.sims_tensor(dino_all, Tl))
+                if halo_rows is not None:
+                    sims_parts.append(e.sims_tensor(torch.cat([dino_all[(Tl - 1) * P: Tl * P], halo_rows], 0), 2))
+            elif n_d >= 2:
+                sims_parts.append(e.sims_tensor(dino_all, n_d))
+            sims_local = torch.cat(sims_parts, 0) if sims_parts else \
+                torch.zeros(0, dtype=torch.float32, device=dino_all.device)
             # the local SigLIP tower is enqueued before the exchange: the device works while the similarities travel
             sig = e.tower("siglip", px_siglip_local)
             counts = [(h - l) - (0 if r < world - 1 else 1) for r, (l, h) in enumerate(ranges)]

@@ -122,11 +122,12 @@ def _case(name):
     return eng, vid, audio, cap
 
 
-def _run_rank(eng, vid, audio, cap, rank, world, comm=None):
+def _run_rank(eng, vid, audio, cap, rank, world, comm=None, halo=False):
     sh = ShardedVideoEncoder(eng, rank, world, comm=comm)
-    fp = sh.frame_plan(vid.shape[0], budget_text_len=4, frame_cap=cap)
+    fp = sh.frame_plan(vid.shape[0], budget_text_len=4, frame_cap=cap, halo=halo)
     return sh.encode_video(vid[fp["siglip_frames"]], vid[fp["dino_frames"]], fp["T"], (384, 384), n_text_tokens=4,
-                           prompt_ids=[1, 2], audio=audio, sample_indices=fp["sample_indices"])
+                           prompt_ids=[1, 2], audio=audio, sample_indices=fp["sample_indices"],
+                           recompute_halo=fp["recompute_halo"])
 
 
 def _serial(name):
@@ -182,7 +183,7 @@ def test_sharded_equals_serial_world2(name):
         assert torch.equal(res[r], want), "rank %d differs" % r
 
 
-def _threads(name, world):
+def _threads(name, world, halo=False):
     import threading
     from util import ThreadComm
     hub = ThreadComm.Hub(world)
@@ -191,7 +192,7 @@ def _threads(name, world):
     def run(r):
         try:
             eng, vid, audio, cap = _case(name)
-            out[r] = _run_rank(eng, vid, audio, cap, r, world, comm=ThreadComm(hub, r))
+            out[r] = _run_rank(eng, vid, audio, cap, r, world, comm=ThreadComm(hub, r), halo=halo)
         except BaseException as ex:      # noqa: BLE001 - release the peers, report in the main thread
             err.append((r, ex))
             hub.bar.abort()
@@ -215,11 +216,22 @@ def test_sharded_equals_serial_any_world(name, world):
         assert got.shape == want.shape and torch.equal(got, want), "rank %d of %d differs" % (r, world)
 
 
+@pytest.mark.parametrize("name", ["plain61", "cap90_audio"])
+def test_boundary_frame_reencoded_instead_of_exchanged(name):
+    """frame_plan(halo=True): the caller hands every rank the next rank's first frame and it is re-encoded locally (round 1's
+    form) - same stream as the exchange of its DINOv2 features"""
+    want = _serial(name)
+    for r, got in enumerate(_threads(name, 4, halo=True)):
+        assert got.shape == want.shape and torch.equal(got, want), "rank %d differs" % r
+
+
 def test_cases_exercise_what_they_claim():
     eng, vid, audio, cap = _case("cap90_audio")
     sh = ShardedVideoEncoder(eng, 1, 4, comm=object())
     fp = sh.frame_plan(90, 4, cap)
     assert fp["T"] == 37 and sum(fp["sample_indices"]) == 37 and len(fp["sample_indices"]) == 90
+    assert fp["dino_frames"] == fp["siglip_frames"]
+    fp = sh.frame_plan(90, 4, cap, halo=True)
     assert fp["dino_frames"][:-1] == fp["siglip_frames"] and len(fp["dino_frames"]) == len(fp["siglip_frames"]) + 1
     eng, vid, _, cap = _case("budget120")
     assert seg.get_max_num_frames(4, eng.cfg) < 120                 # the token budget, not frame_cap, limits the frames
