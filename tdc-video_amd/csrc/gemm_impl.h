@@ -34,6 +34,7 @@ struct GemmArgs {
     RowMap am, cm, rm;
     int tiles_m, tiles_n;
     int debug;   // tdc_gemm_set_debug(): 1 = skip the epilogue, 2 = direct (un-staged) epilogue - timing experiments only
+    int group_m;             // tile rows per group of the grouped tile order (tile_coords); TDC_GEMM_GROUP_M, default 8
     int stagger_ticks;       // persistent kernel: start offset between the tile-column groups of an XCD, in 10-ns ticks (0 = off)
     int stagger_xcd_ticks;   // ... and between the XCDs
     // LayerNorm fusion (see EpiOps / slot_stats_*): producer side x16 + ln_part, consumer side ln_stats + ln_c1
@@ -399,8 +400,8 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[MI][NJ]
 // group of rows.  The 32 workgroups that one XCD runs concurrently (consecutive ids after xcd_remap) then cover an
 // 8 x 4 patch of tiles: 8 activation panels + 4 weight panels stream through that XCD's L2 instead of 1 + 32
 // (PMC, N = 8192: 9.6x the algorithmic bytes crossed the fabric with the plain row-major order).
-constexpr int GROUP_M = 8;
-__device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
+constexpr int GROUP_M_DEFAULT = 8;
+__device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, int& tm, int& tn, int GROUP_M = GROUP_M_DEFAULT) {
     const int per_group = GROUP_M * tiles_n;
     const int grp = id / per_group, within = id - grp * per_group;
     const int first = grp * GROUP_M;
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     const int nwg = p.tiles_m * p.tiles_n;
     const int id = xcd_remap(blockIdx.x, nwg);
     int tm, tn;
-    tile_coords(id, p.tiles_m, p.tiles_n, tm, tn);
+    tile_coords(id, p.tiles_m, p.tiles_n, tm, tn, p.group_m);
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- staging addresses: wave w issues 4 glds for A and 4 for W per K tile; instruction i covers rows 8i..8i+7
@@ -998,7 +999,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     const int nwg = p.tiles_m * p.tiles_n;
     const int id = xcd_remap(blockIdx.x, nwg);
     int tm, tn;
-    tile_coords(id, p.tiles_m, p.tiles_n, tm, tn);
+    tile_coords(id, p.tiles_m, p.tiles_n, tm, tn, p.group_m);
     const int m0 = tm * 256, n0 = tn * 256;
 #ifdef TDC_GEMM_DIAG
     if (p.stamps && threadIdx.x == 0) {
@@ -1352,7 +1353,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
 
     int id = chunk_base + l;
     int tm, tn;
-    tile_coords(id, p.tiles_m, p.tiles_n, tm, tn);
+    tile_coords(id, p.tiles_m, p.tiles_n, tm, tn, p.group_m);
     int m0 = tm * 256, n0 = tn * 256;
     // lane L keeps the epilogue operands of the tile being computed (EpiLane: column n0 + wn*64 + L, rows m0 + wm*128 +
     // L and + 64 + L); the first set is waited for here, compiler-visibly, before any staging load is in flight
@@ -1396,7 +1397,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
         int m1 = 0, n1 = 0;
         if (more) {
             int tm1, tn1;
-            tile_coords(id + G8, p.tiles_m, p.tiles_n, tm1, tn1);
+            tile_coords(id + G8, p.tiles_m, p.tiles_n, tm1, tn1, p.group_m);
             m1 = tm1 * 256; n1 = tn1 * 256;
         }
 #pragma unroll
@@ -1547,6 +1548,11 @@ int launch(const tdc_gemm_desc* d, hipStream_t st) {
     a.debug = tdc_gemm_debug_mode;
     a.stagger_ticks = 0;
     a.stagger_xcd_ticks = 0;
+    {
+        static int gm = -1;
+        if (gm < 0) { const char* e = getenv("TDC_GEMM_GROUP_M"); gm = e ? atoi(e) : GROUP_M_DEFAULT; if (gm < 1) gm = GROUP_M_DEFAULT; }
+        a.group_m = gm;
+    }
 #ifdef TDC_GEMM_DIAG
     { const char* e = getenv("TDC_GEMM_DIAGMODE"); a.diag_mode = e ? atoi(e) : 0; }
 #endif
