@@ -1548,11 +1548,7 @@ int launch(const tdc_gemm_desc* d, hipStream_t st) {
     a.debug = tdc_gemm_debug_mode;
     a.stagger_ticks = 0;
     a.stagger_xcd_ticks = 0;
-    {
-        static int gm = -1;
-        if (gm < 0) { const char* e = getenv("TDC_GEMM_GROUP_M"); gm = e ? atoi(e) : GROUP_M_DEFAULT; if (gm < 1) gm = GROUP_M_DEFAULT; }
-        a.group_m = gm;
-    }
+    a.group_m = GROUP_M_DEFAULT;
 #ifdef TDC_GEMM_DIAG
     { const char* e = getenv("TDC_GEMM_DIAGMODE"); a.diag_mode = e ? atoi(e) : 0; }
 #endif
@@ -1566,6 +1562,15 @@ int launch(const tdc_gemm_desc* d, hipStream_t st) {
     if (use_256(a.M, a.N, a.K)) {
         a.tiles_m = (a.M + 255) / 256;
         a.tiles_n = (a.N + 255) / 256;
+        {   // group height of the tile order: the 32 concurrent tiles of an XCD form a GROUP_M x (32 / GROUP_M) patch that walks
+            // along the columns of its GROUP_M tile rows.  With >= 8 column tiles a 4 x 8 patch keeps the 4 activation panels
+            // L2-resident from one round to the next (PMC, fabric bytes / algorithmic bytes: N = 8192 5.06 -> 4.22, N = 3456
+            // 3.22 -> 2.51, N = 4352 2.59 -> 2.28; 0.8 % faster); the 5- and 6-column GEMMs are better off at 8 (2.39 vs 2.63).
+            // TDC_GEMM_GROUP_M overrides.  The order never changes a result.
+            static int gm_env = -2;
+            if (gm_env == -2) { const char* e = getenv("TDC_GEMM_GROUP_M"); gm_env = e ? atoi(e) : 0; }
+            a.group_m = gm_env > 0 ? gm_env : (a.tiles_n >= 8 ? 4 : 8);
+        }
         // hipFuncSetAttribute is per device: one flag per device and instantiation
         const int dev = current_device();
         static bool attr256_dev[kMaxDev];
