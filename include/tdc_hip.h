@@ -109,7 +109,7 @@ typedef struct {
 } tdc_ln_desc;
 int tdc_layernorm(const tdc_ln_desc* d, void* stream);
 
-/* softmax(Q K^T * scale) V, no mask.  Q element (b, s, h, c) at q + b*q_bs + s*q_rs + h*head_dim + c (same for
+/* softmax(Q K^T * scale) V (no mask but the optional key padding mask of the biased form).  Q element (b, s, h, c) at q + b*q_bs + s*q_rs + h*head_dim + c (same for
  * k, v, o).  head_dim <= 80 (TDC_E_BADARG above).  Replaces HF SigLIP/DINOv2 attention (HF:models/siglip/modeling_siglip.py:273-308),
  * BertSelfAttention self and cross (tdc/Qformer.py:169-275). */
 typedef struct {
@@ -123,6 +123,10 @@ typedef struct {
      * (tdc/audio_models/beats/backbone.py:650-661); needs sk % 4 == 0, head_dim <= 64. */
     const float* bias; long long bias_hs; int bias_rs;
     const float* gate; int gate_rs;
+    /* optional key padding mask of the biased form (NULL = none; needs `bias`): key k of batch item b is excluded from the
+     * softmax (score -inf BEFORE the bias is added, backbone.py:633-643) when key_mask[b*key_mask_bs + k] != 0.
+     * key_mask_bs % 4 == 0, 4-byte aligned.  BEATs padded batches (BEATs.py:142-153: padding_mask of extract_features). */
+    const unsigned char* key_mask; long long key_mask_bs;
 } tdc_attn_desc;
 int tdc_attention(const tdc_attn_desc* d, void* stream);
 

@@ -153,11 +153,25 @@ class BeatsEncoder:
             self._bias[Lq] = self.rel_emb[bucket].permute(2, 0, 1).contiguous().to(self.dev)
         return self._bias[Lq]
 
+    @staticmethod
+    def forward_padding_mask(n_feat, mask):
+        """BEATs.py:102-115 on the host: sample (or frame) mask [B, n] -> one flag per feature = all of its share padded."""
+        extra = mask.shape[1] % n_feat
+        if extra > 0:
+            mask = mask[:, :-extra]
+        return mask.reshape(mask.shape[0], n_feat, -1).all(-1)
+
     def extract_features(self, wav, padding_mask=None, keep=None):
-        """wav [B, n] fp16/fp32 (amplitude +-1) -> [B, L, C] 16-bit.  padding_mask must be None / all False (the
-        reference's single-video path never pads: processor.py:69-72 pads only across batch samples)."""
-        if padding_mask is not None and bool(torch.as_tensor(padding_mask).bool().any()):
-            raise NotImplementedError("padded audio batches: encode each waveform on its own length")
+        """wav [B, n] fp16/fp32 (amplitude +-1) -> [B, L, C] 16-bit.  padding_mask [B, n] bool (True = padded sample, the
+        `audio_wav_mask` of tdc/cambrian_arch.py:1558) or None: reduced to one flag per fbank frame and then per token
+        (BEATs.py:142-153); flagged tokens are zeroed before the positional conv (backbone.py:111-112) and excluded as keys
+        from every layer's attention (backbone.py:633-643) - their own output rows are still computed and returned, as in the
+        reference."""
+        pm = None
+        if padding_mask is not None:
+            pm = torch.as_tensor(padding_mask).bool().cpu()
+            if not bool(pm.any()):
+                pm = None
         dt, dev = self.dtype, self.dev
         wav = wav.to(dev)
         if wav.dtype not in (torch.float16, torch.float32):
@@ -168,17 +182,31 @@ class BeatsEncoder:
         patches, plain, m = ops.fbank(wav, self.tables, dt, want_plain=keep is not None, mean=FBANK_MEAN, std=FBANK_STD)
         Lq = (m // 16) * 8
         R = B * Lq
+        tok_mask = rows_masked = None
+        if pm is not None:
+            assert tuple(pm.shape) == tuple(wav.shape), "padding_mask must match wav"
+            tm = self.forward_padding_mask(Lq, self.forward_padding_mask(m, pm))           # [B, Lq] on the host
+            if bool(tm.any()):
+                assert Lq % 4 == 0, "key padding mask: token count must be a multiple of 4"
+                tok_mask = tm.to(torch.uint8).contiguous().to(dev)
+                rows_masked = torch.nonzero(tm.reshape(-1)).flatten().to(dev)             # token rows b*Lq + t
         f = ops.gemm(patches, self.patch.w, self.patch.b)                                # [R, pad64(E)]
         f16, _ = ops.layernorm(f, self.ln0[0], self.ln0[1], self.eps, self.E, dt)
         # ---- conv positional embedding
         pad, Lp = kk // 2, Lq + kk
         cmap = (Lq, Lp, pad, 1)                                                          # token (b, t) -> row b*Lp + pad + t
         x32 = ops.gemm(f16, self.post.w, self.post.b, out_f32=True)                      # residual of the conv block
+        rows_padded = None
+        if rows_masked is not None:                                                      # x[padding_mask] = 0
+            x32.index_fill_(0, rows_masked, 0.0)
+            rows_padded = (rows_masked // Lq) * Lp + pad + rows_masked % Lq
         xg = torch.zeros(G, B * Lp, cg, device=dev, dtype=dt)                            # zero rows = conv padding
         ypad = torch.empty(B * Lp, Cp, device=dev, dtype=dt)
         Mc = B * Lp - kk + 1
         for g in range(G):
             ops.gemm(f16, self.post.w[g * cg:(g + 1) * cg], self.post.b[g * cg:(g + 1) * cg], out=xg[g], c_map=cmap)
+            if rows_padded is not None:
+                xg[g].index_fill_(0, rows_padded, 0.0)
             a = torch.as_strided(xg[g], (Mc, kk * cg), (cg, 1))                          # overlapping windows
             ops.gemm(a, self.conv_w[g], self.conv_b[g * cg:(g + 1) * cg], act=L.ACT_GELU_ERF,
                      out=ypad[:, g * cg:(g + 1) * cg], M=Mc)
@@ -187,6 +215,8 @@ class BeatsEncoder:
                                add=x32, add_period=R, add_mode=0)
         # ---- layers
         bias = self.position_bias(Lq) if self.rel else None
+        if tok_mask is not None and bias is None:
+            raise NotImplementedError("key padding mask without the relative position bias (tdc_attention: biased form only)")
         eps2 = self.eps / (self.alpha * self.alpha)
         ldq = None
         for Lr in self.layers:
@@ -202,7 +232,8 @@ class BeatsEncoder:
             if Cp != C:
                 attn.zero_()
             ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:3 * C], attn, B, self.heads, self.hd, Lq, Lq,
-                          self.hd ** -0.5, Lq * ldq, Lq * ldq, Lq * ldq, Lq * Cp, bias=bias, gate=gate)
+                          self.hd ** -0.5, Lq * ldq, Lq * ldq, Lq * ldq, Lq * Cp, bias=bias, gate=gate,
+                          key_mask=tok_mask if bias is not None else None)
             y32 = ops.gemm(attn, Lr.out.w, Lr.out.b, res=x16, out_f32=True)
             x16, _ = ops.layernorm(y32, Lr.ln1[0], Lr.ln1[1], eps2, C, dt)
             h = ops.gemm(x16, Lr.fc1.w, Lr.fc1.b, act=L.ACT_GELU_ERF)
@@ -225,12 +256,19 @@ class BeatsEncoder:
             out.append((int(L.load().tdc_fbank_frames(n)) // 16) * 8)
         return out
 
-    def window_features(self, wav, dist=10, only=None):
+    def window_features(self, wav, dist=10, only=None, mask=None):
         """the per-window loop of tdc/cambrian_arch.py:1552-1560 for one video: wav [1, N] -> list of [1, L_w, C].
         All full 10-second windows go through one batched call, a shorter last window through a second one.
         only = iterable of window indices: just those windows are encoded and a dict {window: [1, L_w, C]} comes back
-        (every op of the encoder is row- / item-wise, so a window's features do not depend on what shares its batch)."""
+        (every op of the encoder is row- / item-wise, so a window's features do not depend on what shares its batch).
+        mask [1, N] bool = the `audio_wav_mask` (True = padded sample), sliced per window like the waveform
+        (cambrian_arch.py:1558)."""
         assert wav.dim() == 2 and wav.shape[0] == 1
+        if mask is not None:
+            mask = torch.as_tensor(mask).bool().cpu()
+            assert tuple(mask.shape) == tuple(wav.shape)
+            if not bool(mask.any()):
+                mask = None
         N = wav.shape[1]
         starts = self.window_starts(N, dist)
         sel = list(range(len(starts))) if only is None else sorted(set(int(w) for w in only))
@@ -243,13 +281,17 @@ class BeatsEncoder:
                 batch = wav[0, : len(full) * n].reshape(len(full), n)       # full windows are contiguous from 0
             else:
                 batch = torch.stack([wav[0, SAMPLE_RATE * starts[w]: SAMPLE_RATE * starts[w] + n] for w in full], 0)
-            feats = self.extract_features(batch)
+            bm = None
+            if mask is not None:
+                bm = torch.stack([mask[0, SAMPLE_RATE * starts[w]: SAMPLE_RATE * starts[w] + n] for w in full], 0)
+            feats = self.extract_features(batch, padding_mask=bm)
             for i, w in enumerate(full):
                 out[w] = feats[i:i + 1]
         for w in sel:
             if w not in out:
                 k = starts[w]
-                out[w] = self.extract_features(wav[:, SAMPLE_RATE * k:int(SAMPLE_RATE * (k + dist))])
+                a, b = SAMPLE_RATE * k, int(SAMPLE_RATE * (k + dist))
+                out[w] = self.extract_features(wav[:, a:b], padding_mask=None if mask is None else mask[:, a:b])
         if only is None:
             return [out[w] for w in sel]
         return out

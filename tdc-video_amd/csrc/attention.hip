@@ -189,6 +189,17 @@ __global__ __launch_bounds__(256, (QT <= 2 ? 2 : 1)) void attn_kernel(AttnArgs p
         // ---- online softmax in base 2 on the RAW scores: p = exp2(s*c - m) with c = scale*log2(e) folded into one fma;
         //      keys beyond sk only exist in the last tile (wave-uniform branch)
         v8 pf[QT][2];
+        // key padding mask (biased form only, wave-uniform test): 4 mask bytes per accumulator tile, the same for every query
+        unsigned km[4] = {0u, 0u, 0u, 0u};
+        const bool masked = BIAS && p.kmask != nullptr;
+        if (masked) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                int kc = kv0 + kt * 16 + g * 4;
+                if (PARTIAL && kc > p.sk - 4) kc = p.sk - 4;          // keys beyond sk are masked below anyway
+                km[kt] = *(const unsigned*)(p.kmask + b * p.kmask_bs + kc);
+            }
+        }
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             if (BIAS) {
@@ -201,6 +212,13 @@ __global__ __launch_bounds__(256, (QT <= 2 ? 2 : 1)) void attn_kernel(AttnArgs p
                     if (PARTIAL && kc + g * 4 > p.sk - 4) kc = p.sk - 4 - g * 4;
                     const f32x4 bv = *(const f32x4*)(brow[t] + kc);
                     s[t][kt] = __builtin_elementwise_fma(s[t][kt], c4, gg * bv);
+                }
+                if (masked) {
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if ((km[kt] >> (8 * r)) & 0xffu) s[t][kt][r] = -INFINITY;
                 }
             }
             if (PARTIAL) {
@@ -219,7 +237,8 @@ __global__ __launch_bounds__(256, (QT <= 2 ? 2 : 1)) void attn_kernel(AttnArgs p
             }
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run[t], BIAS ? mx : mx * p.scale_log2);
+            float m_new = fmaxf(m_run[t], BIAS ? mx : mx * p.scale_log2);
+            if (BIAS && m_new == -INFINITY) m_new = 0.f;          // every key so far masked: p = 0, no NaN from inf - inf
             const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
             m_run[t] = m_new;
             const f32x4 nm4 = {-m_new, -m_new, -m_new, -m_new};
@@ -281,10 +300,7 @@ __global__ __launch_bounds__(256, (QT <= 2 ? 2 : 1)) void attn_kernel(AttnArgs p
         for (int dt = 0; dt < NDV; ++dt) {
             const int c = dt * 16 + g * 4;
             if (VEC && c + 3 < d) {
-                v4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (T)(o_acc[t][dt][e] * inv);
-                *(v4*)(orow + c) = o;
+                *(v4*)(orow + c) = cvt4<T>(o_acc[t][dt] * inv);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -361,6 +377,11 @@ extern "C" int tdc_attention(const tdc_attn_desc* d, void* stream) {
                (d->o_rs % 4 == 0) && (d->q_bs % 8 == 0) && (d->k_bs % 8 == 0) && (d->v_bs % 8 == 0) &&
                (d->o_bs % 4 == 0) && al(d->q, 16) && al(d->k, 16) && al(d->v, 16) && al(d->o, 8);
     a.bias = d->bias; a.bias_hs = d->bias_hs; a.bias_rs = d->bias_rs; a.gate = d->gate; a.gate_rs = d->gate_rs;
+    a.kmask = d->key_mask; a.kmask_bs = d->key_mask_bs;
+    if (a.kmask && (!a.bias || d->key_mask_bs % 4 != 0 || d->key_mask_bs < d->sk || !al(d->key_mask, 4))) {
+        fprintf(stderr, "[tdc_hip] tdc_attention: key_mask needs the biased form, key_mask_bs %% 4 == 0 (>= sk) and a 4-byte aligned base\n");
+        return TDC_E_BADARG;
+    }
     if (a.bias) {
         if (!a.gate || d->sk % 4 != 0 || d->sk < 4 || d->bias_rs % 4 != 0 || d->bias_hs % 4 != 0 || !al(d->bias, 16) ||
             d->gate_rs < d->heads) {

@@ -298,10 +298,10 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(AttnArgs p) {
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int col = db * 32 + g4 * 8 + hh * 4;
                 if (col + 3 < d) {
-                    v4 o;
+                    f32x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (T)(o_acc[qb][db][g4 * 4 + e] * inv);
-                    *(v4*)(orow + col) = o;
+                    for (int e = 0; e < 4; ++e) o[e] = o_acc[qb][db][g4 * 4 + e] * inv;
+                    *(v4*)(orow + col) = cvt4<T>(o);
                 }
             }
     }

@@ -14,6 +14,8 @@ struct AttnArgs {
     // bias[h*bias_hs + q*bias_rs + k]; both fp32, bias rows 16-byte aligned (sk % 4 == 0)
     const float* bias; long long bias_hs; int bias_rs;
     const float* gate; int gate_rs;
+    // key padding mask of the biased form: key k of batch b scores -inf when kmask[b*kmask_bs + k] != 0 (NULL = none)
+    const unsigned char* kmask; long long kmask_bs;
 };
 
 // attention32.hip: returns -1 when the 32x32 form does not apply (bias, short sequences, other head dims)

@@ -22,9 +22,26 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 #define TDC_F16 0
 #define TDC_BF16 1
 
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 template <class T> struct VecOf;
-template <> struct VecOf<f16> { typedef f16x8 v8; typedef f16x4 v4; };
-template <> struct VecOf<bf16> { typedef bf16x8 v8; typedef bf16x4 v4; };
+template <> struct VecOf<f16> { typedef f16x8 v8; typedef f16x4 v4; typedef f16x2 v2; };
+template <> struct VecOf<bf16> { typedef bf16x8 v8; typedef bf16x4 v4; typedef bf16x2 v2; };
+
+// fp32 -> 16-bit (round to nearest even, the same result as an elementwise (T) cast) on explicit PAIRS: one
+// v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 per two values.  Written as four scalar casts, plain -O3 pairs elements 1 and 2 and
+// converts 0 and 3 alone, then reassembles the registers with v_pk_mov / v_perm / v_alignbit: 10 VALU instructions per four
+// values (with the bias add) instead of 4 - in the GEMM epilogues, where the MFMA pipe idles, that was most of the work.
+template <class T>
+__device__ __forceinline__ typename VecOf<T>::v2 cvt2(float a, float b) {
+    return __builtin_convertvector((f32x2){a, b}, typename VecOf<T>::v2);
+}
+template <class T>
+__device__ __forceinline__ typename VecOf<T>::v4 cvt4(f32x4 v) {
+    const u32x2 r = {__builtin_bit_cast(unsigned, cvt2<T>(v[0], v[1])), __builtin_bit_cast(unsigned, cvt2<T>(v[2], v[3]))};
+    return __builtin_bit_cast(typename VecOf<T>::v4, r);
+}
 
 // D(16x16 f32) += A(16x32) * B(32x16); lane l: A[row l&15][k 8(l>>4)+j], B[k 8(l>>4)+j][col l&15], j=0..7;
 // D[row 4(l>>4)+reg][col l&15].

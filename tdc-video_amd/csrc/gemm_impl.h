@@ -218,9 +218,8 @@ __device__ __forceinline__ void epi_store(const GemmArgs& p, f32x4 v, long long 
             float* c = (float*)p.C + crow * p.ldc + nc;
             c[0] = o0; c[1] = o1;
         } else {
-            typedef __attribute__((ext_vector_type(2))) T v2;
-            v2 o; o[0] = (T)o0; o[1] = (T)o1;
-            *(v2*)((T*)p.C + crow * p.ldc + nc) = o;
+            typedef typename VecOf<T>::v2 v2;
+            *(v2*)((T*)p.C + crow * p.ldc + nc) = cvt2<T>(o0, o1);
         }
         return;
     }
@@ -234,10 +233,7 @@ __device__ __forceinline__ void epi_store(const GemmArgs& p, f32x4 v, long long 
     if (OUTF32) {
         *(f32x4*)((float*)p.C + crow * p.ldc + n) = v;
     } else {
-        typename VecOf<T>::v4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (T)v[e];
-        *(typename VecOf<T>::v4*)((T*)p.C + crow * p.ldc + n) = o;
+        *(typename VecOf<T>::v4*)((T*)p.C + crow * p.ldc + n) = cvt4<T>(v);
     }
 }
 
@@ -287,10 +283,7 @@ __device__ __forceinline__ void epi_tile_emit(const GemmArgs& p, f32x4 (&acc)[MI
             for (int j = 0; j < 4; ++j) {
                 const int n = nbase + j * 16 + g * 4;
                 *(f32x4*)((float*)p.C + (long long)m * p.ldc + n) = v[j];
-                v4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (T)v[j][e];
-                *(v4*)((T*)p.x16 + (long long)m * p.ldx16 + n) = o;
+                *(v4*)((T*)p.x16 + (long long)m * p.ldx16 + n) = cvt4<T>(v[j]);
             }
             if (g == 0) *(float2*)(p.ln_part + 2 * ((long long)slot * p.M + m)) = make_float2(mean, m2);
         }
@@ -568,10 +561,7 @@ __device__ __forceinline__ void epi_staged16(const GemmArgs& p, f32x4 (&acc)[8][
                     } else if (ACT == TDC_ACT_GELU_TANH) {
                         v = gelu_tanh4(v);
                     }
-                    v4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (T)v[e];
-                    *(v4*)(wbase + ii * 2048 + (((j * 2 + (g >> 1)) ^ sw) << 4)) = o;
+                    *(v4*)(wbase + ii * 2048 + (((j * 2 + (g >> 1)) ^ sw) << 4)) = cvt4<T>(v);
                 }
             }
             v8 val[ROWS / 8];
@@ -612,9 +602,7 @@ __device__ __forceinline__ void epi_staged16(const GemmArgs& p, f32x4 (&acc)[8][
                         for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
                     }
                 }
-                v4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (T)v[e];
+                const v4 o = cvt4<T>(v);
                 const int chunk = (j * 2 + (g >> 1)) ^ (r & 7);
                 if (!diag_no_stage) *(v4*)(region + r * 128 + chunk * 16 + (g & 1) * 8) = o;
                 else asm volatile("" ::"v"(o));
@@ -662,10 +650,7 @@ __device__ __forceinline__ void epi_staged_swiglu(const GemmArgs& p, f32x4 (&acc
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const f32x2_t sg = swiglu2(fops.lin(acc[i][j], i, j));
-                    v2 o;
-                    o[0] = (T)sg[0];
-                    o[1] = (T)sg[1];
-                    *(v2*)(wbase + ii * 1024 + ((j ^ wsw) << 4)) = o;
+                    *(v2*)(wbase + ii * 1024 + ((j ^ wsw) << 4)) = cvt2<T>(sg[0], sg[1]);
                 }
             }
             v8 val[ROWS / 16];
@@ -689,10 +674,8 @@ __device__ __forceinline__ void epi_staged_swiglu(const GemmArgs& p, f32x4 (&acc
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const f32x4 v = ops.lin(acc[i][j], i, j);
-                v2 o;
                 const f32x2_t sg = swiglu2(v);
-                o[0] = (T)sg[0];
-                o[1] = (T)sg[1];
+                const v2 o = cvt2<T>(sg[0], sg[1]);
                 // output column within the wave's 32: j*8 + 2g -> 16-B chunk j (4 per row), swizzled with the row
                 const int chunk = j ^ ((r >> 2) & 3);
                 *(v2*)(region + r * 64 + chunk * 16 + g * 4) = o;
@@ -850,10 +833,7 @@ __device__ __forceinline__ void epi_staged32(const GemmArgs& p, f32x4 (&acc)[8][
                 if (EMIT) {
                     float mean, m2;
                     slot_stats_row16(val[q], mean, m2);
-                    v4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (T)val[q][e];
-                    *(v4*)xptr = o;
+                    *(v4*)xptr = cvt4<T>(val[q]);
                     xptr += xstep;
                     if (rk == 0) *(float2*)lptr = make_float2(mean, m2);
                     lptr += 8;
@@ -907,10 +887,7 @@ __device__ __forceinline__ void epi_staged32(const GemmArgs& p, f32x4 (&acc)[8][
                 float mean, m2;
                 slot_stats_row16(val, mean, m2);          // every lane takes part (rows beyond M: clamped duplicates)
                 if (m < p.M) {
-                    v4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (T)val[e];
-                    *(v4*)((T*)p.x16 + (long long)m * p.ldx16 + n) = o;
+                    *(v4*)((T*)p.x16 + (long long)m * p.ldx16 + n) = cvt4<T>(val);
                     if (k == 0) *(float2*)(p.ln_part + 2 * ((long long)slot * p.M + m)) = make_float2(mean, m2);
                 }
             }
@@ -1224,7 +1201,9 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
     // 512 KiB each and their drain runs at the HBM rate).  The tile period is the same for every CU, so a start offset would
     // persist.  Measured (tools/bench_gemm_epi.py, TDC_GEMM_STAGGER_NS / TDC_GEMM_STAGGER_XCD_NS): offsetting the four
     // tile-column groups of an XCD shortens the drain but costs the main loop as much (the groups stop sharing operand
-    // panels in flight in L2): no net gain at 1-8 us.
+    // panels in flight in L2): no net gain at 1-8 us.  Splitting an XCD's CUs into two half-sets on disjoint halves of the
+    // XCD's chunk (each keeps its own operand sharing), the second set starting about half a tile period late: 2-3 % SLOWER
+    // on every tower shape (main loops 397 -> 412 ms per 256 frames, epilogue share unchanged) - removed again.
     if (p.stagger_ticks > 0 || p.stagger_xcd_ticks > 0) {
         const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)((l >> 3) & 3) * p.stagger_ticks +
                                          (unsigned long long)xcd * p.stagger_xcd_ticks;

@@ -91,10 +91,7 @@ __global__ __launch_bounds__(256) void ln_kernel(LnArgs p) {
             osq += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
         } else if (c < p.pad_cols) {
             if (p.y16) {
-                v4 h;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = (T)o[e];
-                *(v4*)((T*)p.y16 + yrow * p.ldy16 + c) = h;
+                *(v4*)((T*)p.y16 + yrow * p.ldy16 + c) = cvt4<T>(o);
             }
             if (p.y32) *(f32x4*)(p.y32 + yrow * p.ldy32 + c) = o;
         }

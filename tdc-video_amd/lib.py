@@ -43,7 +43,8 @@ class AttnDesc(C.Structure):
                 ("batch", C.c_int), ("heads", C.c_int), ("head_dim", C.c_int), ("sq", C.c_int), ("sk", C.c_int),
                 ("scale", C.c_float), ("dtype", C.c_int),
                 ("bias", C.c_void_p), ("bias_hs", C.c_longlong), ("bias_rs", C.c_int),
-                ("gate", C.c_void_p), ("gate_rs", C.c_int)]
+                ("gate", C.c_void_p), ("gate_rs", C.c_int),
+                ("key_mask", C.c_void_p), ("key_mask_bs", C.c_longlong)]
 
 
 class GatherTables(C.Structure):

@@ -21,6 +21,7 @@ from abc import ABC, abstractmethod
 import torch
 import torch.nn as nn
 
+from . import lib as L
 from . import segment as seg
 from .pipeline import VideoEncoder
 
@@ -221,7 +222,12 @@ class BeatsHandle:
             from .beats import BeatsEncoder
             self._enc = BeatsEncoder(self.state, self.cfg, dtype=dtype,
                                      device=device or ("cuda:%d" % torch.cuda.current_device()))
-        return self._enc.extract_features(source, padding_mask), padding_mask
+        feats = self._enc.extract_features(source, padding_mask)
+        if padding_mask is not None:         # the reference hands back the mask reduced to one flag per token (BEATs.py:142-153)
+            pm = torch.as_tensor(padding_mask).bool()
+            frames = int(L.load().tdc_fbank_frames(int(pm.shape[1])))
+            padding_mask = self._enc.forward_padding_mask(feats.shape[1], self._enc.forward_padding_mask(frames, pm))
+        return feats, padding_mask
 
 
 class AudioEncoderHandle:

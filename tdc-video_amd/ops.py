@@ -226,10 +226,12 @@ def layernorm(x, gamma, beta, eps, cols, dtype, y16=None, y32=None, add=None, ad
     return y16, y32
 
 
-def attention(q, k, v, out, batch, heads, head_dim, sq, sk, scale, q_bs, k_bs, v_bs, o_bs, bias=None, gate=None):
+def attention(q, k, v, out, batch, heads, head_dim, sq, sk, scale, q_bs, k_bs, v_bs, o_bs, bias=None, gate=None,
+              key_mask=None):
     """q/k/v/out: 2-D views [tokens, ld] whose element (b, s, h, c) sits at base + b*bs + s*stride(0) + h*head_dim + c.
     Tensors may be column-offset views of a fused QKV buffer.  bias fp32 [heads, sq, sk] + gate fp32 [batch*sq, >=heads]
-    add gate[b*sq+q, h] * bias[h, q, k] to the scaled scores (BEATs gated relative position bias)."""
+    add gate[b*sq+q, h] * bias[h, q, k] to the scaled scores (BEATs gated relative position bias); key_mask uint8 / bool
+    [batch, sk] (biased form only): non-zero = key excluded from the softmax (key padding mask)."""
     for t in (q, k, v, out):
         assert t.is_cuda and t.dim() == 2 and t.stride(1) == 1
     assert q.dtype == k.dtype == v.dtype == out.dtype
@@ -253,6 +255,11 @@ def attention(q, k, v, out, batch, heads, head_dim, sq, sk, scale, q_bs, k_bs, v
         assert head_dim <= 64 and head_dim % 8 == 0
         d.bias, d.bias_hs, d.bias_rs = bias.data_ptr(), sq * sk, sk
         d.gate, d.gate_rs = gate.data_ptr(), gate.stride(0)
+    if key_mask is not None:
+        assert bias is not None, "key_mask: biased form only"
+        assert key_mask.is_cuda and key_mask.dtype in (torch.uint8, torch.bool) and key_mask.is_contiguous()
+        assert tuple(key_mask.shape) == (batch, sk)
+        d.key_mask, d.key_mask_bs = key_mask.data_ptr(), sk
     e0 = _prof_begin("attn")
     L.check(L.load().tdc_attention(C.byref(d), _stream()), "tdc_attention")
     _prof_end("attn", e0, 4.0 * batch * heads * sq * sk * head_dim)

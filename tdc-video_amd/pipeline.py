@@ -476,9 +476,7 @@ class VideoEncoder:
         only = set of window indices -> dict {window: features} of just those windows."""
         if getattr(self, "beats", None) is None:
             raise RuntimeError("raw audio given but no BEATs encoder is attached (VideoEncoder.beats)")
-        if mask is not None and bool(torch.as_tensor(mask).bool().any()):
-            raise NotImplementedError("padded audio (audio_wav_mask with True entries)")
-        return self.beats.window_features(wav, only=only)
+        return self.beats.window_features(wav, only=only, mask=mask)
 
     def local_audio(self, audio, sample_indices, T, lo=0, hi=None):
         """a20 for the frames [lo, hi) of the T kept frames: the caller's `audio` (None, a [T, 50, 768] token tensor, or

@@ -76,6 +76,20 @@ def test_relpos_gate_and_biased_attention():
         want = (torch.softmax(sc, -1) @ vh).transpose(1, 2).reshape(B * S, C)
         tol = 2e-3 if dt == torch.float16 else 1.2e-2
         assert rel(out, want) < tol, (B, H, d, S, rel(out, want))
+        # key padding mask (backbone.py:633-643): a padded tail per batch item + one isolated key, masked before the bias
+        km = torch.zeros(B, S, dtype=torch.bool)
+        for bi in range(B):
+            km[bi, S - min(5 + 37 * bi, S // 3):] = True
+        km[0, 3] = True
+        if B > 1:
+            km[1, : 70 if S > 200 else 9] = True                  # (S > 200) a whole leading K/V tile masked: running max starts at -inf
+        outm = torch.zeros(B * S, C, dtype=dt, device="cuda")
+        ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], outm, B, H, d, S, S, d ** -0.5, S * ld, S * ld, S * ld,
+                      S * C, bias=bias.cuda().contiguous(), gate=gate, key_mask=km.cuda())
+        scm = sc.masked_fill(km[:, None, None, :], float("-inf"))
+        wantm = (torch.softmax(scm, -1) @ vh).transpose(1, 2).reshape(B * S, C)
+        assert rel(outm, wantm) < tol, (B, H, d, S, rel(outm, wantm))
+        assert not torch.equal(outm, out)
 
 
 @pytest.mark.parametrize("tag", ["a", "b"])
@@ -89,8 +103,51 @@ def test_tiny_encoder_vs_reference_fixture(tag):
     assert tuple(out.shape) == tuple(ref.shape)
     assert float((keep["fbank"].cpu() - torch.from_numpy(o["fbank_" + tag])).abs().max()) < 2e-3
     assert rel(out, ref) < 1e-2, rel(out, ref)
-    with pytest.raises(NotImplementedError):
-        enc.extract_features(wav, padding_mask=torch.ones(wav.shape, dtype=torch.bool))
+
+
+def test_padded_batch_vs_reference_fixture():
+    """extract_features with a padding mask (BEATs.py:142-153, backbone.py:111-112,633-643): the reference's output on a
+    padded 2-sample batch (tests/golden/make_golden_beats.py)."""
+    W, cfg, o = load_beats_fixture()
+    enc = _enc(W, cfg)
+    wav = torch.from_numpy(o["wav_pad"])
+    mask = torch.from_numpy(o["mask_pad"])
+    out = enc.extract_features(wav, padding_mask=mask)
+    ref = torch.from_numpy(o["out_pad"])
+    tokm = torch.from_numpy(o["tokmask_pad"])
+    assert tuple(out.shape) == tuple(ref.shape) and bool(tokm.any())
+    assert torch.equal(enc.forward_padding_mask(ref.shape[1], enc.forward_padding_mask(
+        BO.preprocess(wav.float()).shape[1], mask)), tokm)
+    valid = ~tokm
+    err = float((out.float().cpu() - ref)[valid].abs().max()) / float(ref[valid].abs().max())
+    assert err < 1e-2, err
+    # the mask matters: without it the valid tokens of the padded item come out different
+    plain = enc.extract_features(wav)
+    assert float((plain.float().cpu() - ref)[valid].abs().max()) / float(ref[valid].abs().max()) > 2 * err
+    # the unpadded item of the batch is the unmasked computation
+    b_full = int(torch.nonzero(~tokm.any(1))[0])
+    assert torch.equal(out[b_full], plain[b_full])
+
+
+def test_window_features_with_padding_mask():
+    """the per-window loop of cambrian_arch.py:1552-1560 slices audio_wav_mask like the waveform: a padded tail in the last
+    full window and in the short window; each window equals the direct call on its slice."""
+    W, cfg, o = load_beats_fixture()
+    enc = _enc(W, cfg)
+    g = torch.Generator().manual_seed(5)
+    N = 16000 * 23 + 800
+    wav = (0.1 * torch.randn(1, N, generator=g)).half()
+    mask = torch.zeros(1, N, dtype=torch.bool)
+    mask[0, 16000 * 17: 16000 * 20] = True
+    mask[0, 16000 * 22:] = True
+    got = enc.window_features(wav, mask=mask)
+    assert len(got) == 3
+    for w, (a, b) in enumerate([(0, 160000), (160000, 320000), (320000, N)]):
+        want = enc.extract_features(wav[:, a:b], padding_mask=mask[:, a:b])
+        assert torch.equal(got[w], want)
+    assert torch.equal(got[0], enc.window_features(wav)[0])
+    sel = enc.window_features(wav, only=[1], mask=mask)
+    assert torch.equal(sel[1], got[1])
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 1e-2), (torch.bfloat16, 6e-2)])
