@@ -248,10 +248,10 @@ __global__ __launch_bounds__(256, (QT <= 2 ? 2 : 1)) void attn_kernel(AttnArgs p
                 const f32x4 z = BIAS ? s[t][kt] + nm4 : __builtin_elementwise_fma(s[t][kt], c4, nm4);   // v_pk_fma_f32
                 f32x4 e;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    e[r] = __builtin_amdgcn_exp2f(z[r]);
-                    pf[t][kt >> 1][(kt & 1) * 4 + r] = (T)e[r];
-                }
+                for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(z[r]);
+                const typename VecOf<T>::v4 e16 = cvt4<T>(e);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pf[t][kt >> 1][(kt & 1) * 4 + r] = e16[r];
                 rs4 += e;                                                       // v_pk_add_f32
             }
             const float rs = (rs4[0] + rs4[1]) + (rs4[2] + rs4[3]);

@@ -226,8 +226,9 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(AttnArgs p) {
                         const f32x2_t z = __builtin_elementwise_fma((f32x2_t){s[qb][kb][st * 8 + j], s[qb][kb][st * 8 + j + 1]}, c2, nm2);
                         const f32x2_t e = {__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])};
                         rs2 += e;
-                        pf[qb][kb][st][j] = (T)e[0];
-                        pf[qb][kb][st][j + 1] = (T)e[1];
+                        const typename VecOf<T>::v2 e16 = cvt2<T>(e[0], e[1]);     // one v_cvt_pk per pair, f16 too
+                        pf[qb][kb][st][j] = e16[0];
+                        pf[qb][kb][st][j + 1] = e16[1];
                     }
             l_run[qb] = l_run[qb] * alpha + (rs2[0] + rs2[1]);
             // the running max only moves in the first few tiles: skip the O rescale when no lane's max changed

@@ -129,6 +129,22 @@ def test_padded_batch_vs_reference_fixture():
     assert torch.equal(out[b_full], plain[b_full])
 
 
+def test_beats_handle_returns_token_mask():
+    """model.BeatsHandle.extract_features mirrors BEATs.extract_features(feature_only=True): (features, token-level mask)."""
+    import tdc_video_amd  # noqa: F401
+    from tdc_video_amd.model import BeatsHandle
+    W, cfg, o = load_beats_fixture()
+    h = BeatsHandle(cfg, W)
+    wav, mask = torch.from_numpy(o["wav_pad"]), torch.from_numpy(o["mask_pad"])
+    feats, pm = h.extract_features(wav, padding_mask=mask, feature_only=True)
+    assert torch.equal(pm, torch.from_numpy(o["tokmask_pad"]))
+    assert torch.equal(feats, _enc(W, cfg).extract_features(wav, padding_mask=mask))
+    feats0, pm0 = h.extract_features(wav)
+    assert pm0 is None and tuple(feats0.shape) == tuple(feats.shape)
+    with pytest.raises(NotImplementedError):
+        h.extract_features(wav, feature_only=False)
+
+
 def test_window_features_with_padding_mask():
     """the per-window loop of cambrian_arch.py:1552-1560 slices audio_wav_mask like the waveform: a padded tail in the last
     full window and in the short window; each window equals the direct call on its slice."""
