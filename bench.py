@@ -185,6 +185,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tower-batch", type=int, default=512)
     ap.add_argument("--two-streams", type=int, default=0, help="run the two towers on two HIP streams")
+    ap.add_argument("--gemm-shape-times", default="", help="write per-shape GEMM times of the profiled step to this file")
     ap.add_argument("--audio", action="store_true", help="BASELINE config 4: + T seconds of 16 kHz audio through BEATs "
                     "on the device, 50 audio tokens per frame in the Q-Former KV (1 GPU only)")
     ap.add_argument("--dump-gemm-shapes", default=None, help="write the GEMM launches of one step (for tools/gemm_pmc)")
@@ -297,6 +298,16 @@ def main():
         with open(args.dump_gemm_shapes, "w") as fh:
             for (M_, N_, K_, act_, res_, of_), c in sorted(cnt.items(), key=lambda kv: -kv[0][0] * kv[0][1] * kv[0][2] * kv[1]):
                 fh.write("%d %d %d %d %d %d %d\n" % (M_, N_, K_, act_, res_, of_, c))
+    if args.gemm_shape_times and rank == 0 and len(prof["gemm_shapes"]) == len(prof["gemm"]):
+        import collections
+        agg = collections.OrderedDict()
+        for shp, (e0, e1, w) in zip(prof["gemm_shapes"], prof["gemm"]):
+            a = agg.setdefault(shp, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += w
+        with open(args.gemm_shape_times, "w") as fh:
+            fh.write("# M N K act res out_f32 | launches, total ms of the profiled step, TFLOP/s (real dims)\n")
+            for shp, (c, ms_, w) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                fh.write("%7d %5d %5d %d %d %d | %4d %9.3f ms %8.1f TF/s\n" % (shp + (c, ms_, w / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0)))
     g_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof["gemm"])
     g_fl = sum(w for _, _, w in prof["gemm"])
     a_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof["attn"])
