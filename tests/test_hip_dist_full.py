@@ -118,10 +118,12 @@ def test_fullsize_sharded_processes_equal_serial(world, audio):
     assert 24 < n_static < T and n_static * (N + 1) + (T - n_static) * (K + 1) == n_tok and res[0][2][1] == H
 
 
-def test_fullsize_sharded_world8_threads_equal_serial():
+@pytest.mark.parametrize("per_rank", [PER_RANK, 64])
+def test_fullsize_sharded_world8_threads_equal_serial(per_rank):
+    """per_rank = 64 is BASELINE config 3 at its own size: one 512-frame video, 64 frames per rank, world 8."""
     from test_hip_dist2 import run_threads
     world = 8
-    T = PER_RANK * world
+    T = per_rank * world
     engines = [_engine(T)[0] for _ in range(world)]
     want = _serial(engines[0], None, T)
     got = run_threads(world, lambda r, comm: _sharded(engines[r], None, T, r, world, comm=comm))
