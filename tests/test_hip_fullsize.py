@@ -242,6 +242,16 @@ def test_fullsize_video_plus_audio_token_accounting(full):
         assert n_static + n_comp == T and n_comp > 0
         assert a.shape[0] == n_static * (N + 50 + 1) + n_comp * (K + 1)
         assert torch.isfinite(a.float()).all()
+        # padded audio (audio_wav_mask True on the tail of the last full window and the short one): same layout, finite, and
+        # different from the unpadded encode only from the first frame whose BEATs window holds padding
+        mask = torch.zeros(wav.shape, dtype=torch.bool)
+        mask[0, 16000 * (T - 7):] = True
+        m = run(enc, vs, vd, audio={"audio_wav": wav, "audio_wav_mask": mask})
+        assert m.shape == a.shape and torch.isfinite(m.float()).all() and not torch.equal(m, a)
+        first_bad = int(torch.nonzero((m != a).any(1))[0])
+        keys = set(int(f) for f in plan["key_frames"])
+        rows_before = sum((N + 50 + 1) if f in keys else (K + 1) for f in range(30))   # frames in front of the window 30 s .. 40 s
+        assert first_bad >= rows_before > 0
     finally:
         enc.cfg["audio_input"], enc.c.audio_proj, enc.beats = old
         if old[0] is None:
