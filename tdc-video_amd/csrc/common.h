@@ -137,12 +137,28 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // generic row map: row(m) = (m / seg) * stride + off + (m % seg) * inner ; identity when seg == 0
+// The quotient comes from a host-computed reciprocal (inv = floor(2^32 / seg), a kernel argument = an SGPR) and two
+// corrections: a plain `m / seg` expands into a float-reciprocal sequence whose seg-only part the compiler hoists to kernel
+// entry as a VGPR that then lives through the whole kernel - in the persistent GEMM that register was spilled and its
+// scratch reload at the tile seam waited (in-order vmcnt) for every staged load in flight.
 struct RowMap {
     int seg, stride, off, inner;
-    __device__ __forceinline__ long long operator()(int m) const {
+    unsigned inv;
+    __host__ static RowMap make(int seg, int stride, int off, int inner) {
+        RowMap r;
+        r.seg = seg; r.stride = stride; r.off = off; r.inner = inner;
+        r.inv = seg > 0 ? (unsigned)((1ull << 32) / (unsigned long long)seg > 0xFFFFFFFFull ? 0xFFFFFFFFull
+                                                                                             : (1ull << 32) / (unsigned long long)seg)
+                        : 0u;
+        return r;
+    }
+    __device__ __forceinline__ long long operator()(int m) const {        // m >= 0
         if (seg == 0) return m;
-        int q = m / seg;
-        return (long long)q * stride + off + (long long)(m - q * seg) * inner;
+        unsigned q = __umulhi((unsigned)m, inv);                            // q_true - 2 <= q <= q_true
+        unsigned r = (unsigned)m - q * (unsigned)seg;
+        if (r >= (unsigned)seg) { q += 1; r -= (unsigned)seg; }
+        if (r >= (unsigned)seg) { q += 1; r -= (unsigned)seg; }
+        return (long long)q * stride + off + (long long)r * inner;
     }
 };
 

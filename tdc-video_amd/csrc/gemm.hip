@@ -45,6 +45,7 @@ extern "C" int tdc_gemm(const tdc_gemm_desc* d, void* stream) {
     if ((d->lda % amul) || (d->ldw % amul) || (d->ldc % 4) || (d->res && (d->ldres % 4)) || d->ldw < d->K) return TDC_E_BADARG;
     /* lda < K is legal: rows of A may overlap (sliding-window views, e.g. the BEATs conv positional embedding) */
     if (d->act != TDC_ACT_NONE && d->res) return TDC_E_BADARG;  /* activation epilogues take no residual */
+    if (d->a_map.seg < 0 || d->c_map.seg < 0 || d->r_map.seg < 0) return TDC_E_BADARG;
     if (d->x16) {   /* LayerNorm fusion, producer: fp32 residual-stream update with identity row maps, whole 64-column slots */
         if (!d->ln_part || !d->out_f32 || !d->res || !d->res_f32 || d->act != TDC_ACT_NONE || d->N % 64 != 0 ||
             d->c_map.seg != 0 || d->r_map.seg != 0 || d->ldx16 % 4 != 0 || d->ldx16 < d->N || ((uintptr_t)d->x16 & 7) ||

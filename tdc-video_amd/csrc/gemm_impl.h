@@ -61,6 +61,14 @@ struct GemmArgs {
 #define TDC_STAMP(k)
 #endif
 
+// lane id from v_mbcnt: a fresh value wherever it is needed, no register live from kernel entry (threadIdx.x & 63 kept across
+// the K loop of the persistent kernel gets spilled)
+__device__ __forceinline__ int fresh_lane() {
+    int l;      // volatile: recomputed at every use, never hoisted out of the tile loop (neither it nor what is derived from it)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     // bijective "contiguous chunk per XCD" remap (cdna_hip_programming.md T1): blocks b, b+8, ... share an XCD
     int q = nwg >> 3, r = nwg & 7, x = bid & 7;
@@ -1217,8 +1225,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
         // the lane-derived terms are recomputed from an opaque copy of the lane id on every call (once per tile): kept in
         // registers across the K loop they would be spilled, and a scratch reload at the tile seam waits for every
         // staged load in flight (in-order vmcnt)
-        int sl = lane;
-        asm volatile("" : "+v"(sl));
+        const int sl = fresh_lane();
         const int srow = sl >> 3;
         const int schunk = (sl & 7) ^ srow;
         a_base = (const char*)p.A + (long long)m0 * p.lda * 2;
@@ -1338,12 +1345,14 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
     // L and + 64 + L); the first set is waited for here, compiler-visibly, before any staging load is in flight
     auto load_epi_lane = [&](int m0_, int n0_) {
         EpiLane e = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int n = n0_ + wn_ * 64 + lane;
+        const int ln = fresh_lane();       // not `lane`: kept live across the K loop it is spilled, and its scratch reload here
+                                           // waits (vmcnt(0), in order) for every staged load of the next tile
+        int n = n0_ + wn_ * 64 + ln;
         if (n > p.N - 1) n = p.N - 1;
         if (p.bias) e.bias = p.bias[n];
         if (LNF) {
             if (!kScaleOnly) e.c1 = p.ln_c1[n];
-            int r0 = m0_ + wm * 128 + lane, r1 = r0 + 64;
+            int r0 = m0_ + wm * 128 + ln, r1 = r0 + 64;
             if (r0 > p.M - 1) r0 = p.M - 1;
             if (r1 > p.M - 1) r1 = p.M - 1;
             const float2 s0 = *(const float2*)(p.ln_stats + 2 * (long long)r0);
@@ -1354,8 +1363,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
     };
     // Between its load (one tile ahead, at the start of the previous epilogue) and its use the set is parked in the wave's
     // epilogue staging region, which is idle during the main loop: no VGPR stays live across the K loop for it.
-    EpiLane* el_park = (EpiLane*)(smem + T2_LDS + wave * 4096) + lane;
-    *el_park = load_epi_lane(m0, n0);
+    auto el_park = [&]() { return (EpiLane*)(smem + T2_LDS + wave * 4096) + fresh_lane(); };
+    *el_park() = load_epi_lane(m0, n0);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     // ---- prologue of the first tile: K tile 0 complete + K tile 1's A0 B0 B1
     set_stage_tile(m0, n0);
@@ -1413,8 +1422,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
         // made opaque per tile so that the epilogue's lane-derived addresses are recomputed here instead of being hoisted
         // out of the tile loop, kept live across the main loop and spilled (their scratch reloads would sit behind the
         // next tile's staged loads in the in-order vmcnt queue).
-        int elane = lane;
-        asm volatile("" : "+v"(elane));
+        const int elane = fresh_lane();
 #ifdef TDC_GEMM_DIAG
         if (p.wstamps && lane == 0) {
             __builtin_amdgcn_sched_barrier(0);
@@ -1422,7 +1430,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
             __builtin_amdgcn_sched_barrier(0);
         }
 #endif
-        const EpiLane el = *el_park;
+        const EpiLane el = *el_park();
         EpiLane el_next = el;
         if (more) el_next = load_epi_lane(m1, n1);                       // complete by the vmcnt(0) below
         if (wave_active && p.debug != 1) {
@@ -1465,7 +1473,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
             __builtin_amdgcn_sched_barrier(0);
         }
 #endif
-        *el_park = el_next;
+        *el_park() = el_next;
         id += G8; m0 = m1; n0 = n1;
     }
 }
@@ -1535,9 +1543,9 @@ int launch(const tdc_gemm_desc* d, hipStream_t st) {
     a.stamps = tdc_gemm_diag_stamps;
     a.wstamps = tdc_gemm_diag_wstamps;
 #endif
-    a.am = {d->a_map.seg, d->a_map.stride, d->a_map.off, d->a_map.inner};
-    a.cm = {d->c_map.seg, d->c_map.stride, d->c_map.off, d->c_map.inner};
-    a.rm = {d->r_map.seg, d->r_map.stride, d->r_map.off, d->r_map.inner};
+    a.am = RowMap::make(d->a_map.seg, d->a_map.stride, d->a_map.off, d->a_map.inner);
+    a.cm = RowMap::make(d->c_map.seg, d->c_map.stride, d->c_map.off, d->c_map.inner);
+    a.rm = RowMap::make(d->r_map.seg, d->r_map.stride, d->r_map.off, d->r_map.inner);
     if (use_256(a.M, a.N, a.K)) {
         a.tiles_m = (a.M + 255) / 256;
         a.tiles_n = (a.N + 255) / 256;

@@ -226,8 +226,9 @@ extern "C" int tdc_layernorm(const tdc_ln_desc* d, void* stream) {
         a.add_side = s;
     }
     a.rows = d->rows; a.cols = d->cols;
-    a.xm = {d->x_map.seg, d->x_map.stride, d->x_map.off, d->x_map.inner};
-    a.ym = {d->y_map.seg, d->y_map.stride, d->y_map.off, d->y_map.inner};
+    if (d->x_map.seg < 0 || d->y_map.seg < 0) return TDC_E_BADARG;
+    a.xm = RowMap::make(d->x_map.seg, d->x_map.stride, d->x_map.off, d->x_map.inner);
+    a.ym = RowMap::make(d->y_map.seg, d->y_map.stride, d->y_map.off, d->y_map.inner);
     a.pad_cols = (d->cols + 63) / 64 * 64;
     int ldmin = a.pad_cols;
     if ((d->y16 && d->ldy16 < ldmin) || (d->y32 && d->ldy32 < ldmin) || (d->y8 && d->ldy8 < ldmin)) {
