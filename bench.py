@@ -24,6 +24,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16/fp16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+# what back-to-back bf16 16x16x32 MFMAs on dense random REGISTER operands sustain at the chip's power limit (no memory traffic;
+# all-zero operands: 2448): tools/mfma_power.cpp, profiles/r02_mfma_power.log.  Reported beside `frac`, never instead of it.
+MFMA_DENSE_SUSTAINED_TFLOPS = 1899.0
 PMC_SUMMARY = "r02_gemm_pmc_summary.json"   # profiles/: counters of the current code (tools/run_gemm_pmc.sh), see `traffic_source`
 
 
@@ -350,6 +353,11 @@ def main():
                                     note="(GEMM + attention FLOPs of this rank x ranks) / timed step; peak x ranks"),
                     xattn_kv_gemm_tflops=round(sum(w for _, w in kv) / (sum(t for t, _ in kv) * 1e-3) / 1e12, 1)
                     if kv else None, mfma_busy_pmc=mfma_busy, xattn_kv_mfma_busy_pmc=kv_busy)
+    if args.dtype != "fp8":
+        roofline["power_limited_mfma"] = dict(
+            tflops=MFMA_DENSE_SUSTAINED_TFLOPS, frac=round(achieved / MFMA_DENSE_SUSTAINED_TFLOPS, 4),
+            note="replayed constant, not measured in this run: bf16 16x16x32 MFMAs on dense random register operands, no memory "
+                 "traffic, every CU busy (tools/mfma_power.cpp, profiles/r02_mfma_power.log); all-zero operands reach 2448")
     if rank != 0:
         return
     res = {
