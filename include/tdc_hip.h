@@ -131,17 +131,19 @@ typedef struct {
 int tdc_attention(const tdc_attn_desc* d, void* stream);
 
 /* ---- small data-movement / reduction kernels ------------------------------------------------------------- */
-/* pixels [B,3,H,W] (fp32 or 16-bit) -> patches [B*gh*gw, ldp] 16-bit in conv-weight order (c,ky,kx), zero pad.
+/* pixels [B,3,H,W] (px_f32: 0 = the 16-bit type `dtype`, 1 = fp32, 2 = the OTHER 16-bit type - fp16 frames into bf16
+ * towers) -> patches [B*gh*gw, ldp] 16-bit `dtype` in conv-weight order (c,ky,kx), zero pad.
  * Patch-embed conv as a GEMM (HF:models/siglip/modeling_siglip.py:124-130, dinov2/modeling_dinov2.py:140-151). */
 int tdc_im2col(const void* px, int px_f32, void* patches, int ldp, int B, int H, int W, int patch, int dtype,
                void* stream);
 /* x32 [B, S, ld] rows `row` of every batch := vec[ld] (cls token + pos[0]) */
 int tdc_set_rows(float* x32, int ld, int B, int S, int row, const float* vec, void* stream);
-/* separable 2-tap resample of a token grid: x (fp32 or 16-bit) [B, tok_off + n_in*n_in, ldx] -> y 16-bit
- * [B, n_out*n_out, ldy]; idx0/idx1/frac are device arrays [n_out] (bilinear, align_corners=False; built by host).
+/* separable 2-tap resample of a token grid: x (fp32 or 16-bit `dtype`) [B, tok_off + n_in*n_in, ldx] -> y 16-bit
+ * (`out_dtype`: may differ from `dtype` - bf16 towers feeding an fp16 connector) [B, n_out*n_out, ldy]; idx0/idx1/frac are
+ * device arrays [n_out] (bilinear, align_corners=False; built by host).
  * siglip_encoder.py:43-69, dino_encoder.py:81-107 (and the cls drop of feature_select :66-79). */
 int tdc_resample_tokens(const void* x, int x_f32, int ldx, int tok_off, int n_in, void* y, int ldy, int n_out,
-                        const int* idx0, const int* idx1, const float* frac, int B, int cols, int dtype,
+                        const int* idx0, const int* idx1, const float* frac, int B, int cols, int dtype, int out_dtype,
                         void* stream);
 /* adjacent-frame cosine similarity on flattened features f [T, n] 16-bit: sims[t] = cos(f[t], f[t+1]), t < T-1
  * (tdc/cambrian_arch.py:832-842); n % 8 == 0.  scratch: tdc_frame_cossim_scratch_floats(T) floats.  The reduction
@@ -226,9 +228,12 @@ typedef struct {
                                         (attention output, MLP hidden) quantised per row by tdc_quantize_rows_fp8; 3: as 2, but
                                         fc1 writes the MLP hidden as e4m3 itself (tdc_gemm_desc.out_fp8; needs fc1's output
                                         width == fc2.k) */
+    int out_dtype;                   /* TDC_F16 / TDC_BF16: 16-bit type of tdc_vit_fwd's `out` rows.  Set it explicitly; it may
+                                        differ from `dtype` (the towers - 98 % of the FLOPs - in bf16, the connector and the
+                                        Q-Former behind them in fp16: compressed tokens within 1e-3 of the fp32 oracle) */
 } tdc_vit_model;
 size_t tdc_vit_workspace_bytes(const tdc_vit_model* m, int B, int H, int W);
-/* px [B,3,H,W] (fp32 when px_f32 else 16-bit) -> out [B*out_grid*out_grid, ldo] 16-bit; idx0/idx1/frac: bilinear tables
+/* px [B,3,H,W] (px_f32 as in tdc_im2col: 0 = `dtype`, 1 = fp32, 2 = the other 16-bit type) -> out [B*out_grid*out_grid, ldo] 16-bit `out_dtype`; idx0/idx1/frac: bilinear tables
  * [out_grid] for the (H/patch)-wide grid (device).  H == W required (the reference pads frames to squares). */
 int tdc_vit_fwd(const tdc_vit_model* m, const void* px, int px_f32, int B, int H, int W, int out_grid,
                 const int* idx0, const int* idx1, const float* frac, void* out, int ldo, void* workspace,

@@ -35,8 +35,15 @@ def build(force=False, verbose=True):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
 
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+           [os.path.join(HERE, "..", "include", "tdc_hip.h"), os.path.abspath(__file__)]
+    t_hdr = max(os.path.getmtime(h) for h in hdrs)
+
     def cc(src):
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        # per-object staleness: a translation unit is recompiled when it, a header or this script is newer than its object
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(t_hdr, os.path.getmtime(os.path.join(CSRC, src))):
+            return obj
         cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(src, []) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
@@ -45,10 +52,16 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(cc, sources()))
-    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs,
+    # link to a temporary name and rename into place: a process that starts while the linker is writing never sees (and
+    # dlopens) a partial library
+    tmp = OUT + ".tmp.%d" % os.getpid()
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs,
                        capture_output=True, text=True)
     if r.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError("link failed:\n" + r.stderr)
+    os.replace(tmp, OUT)
     if verbose:
         print("[tdc-video_amd] built", OUT, file=sys.stderr)
     return OUT

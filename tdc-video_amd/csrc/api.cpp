@@ -375,7 +375,8 @@ extern "C" int tdc_vit_fwd(const tdc_vit_model* m, const void* px, int px_f32, i
         src = h16;
         src_f32 = 0;
     }
-    return tdc_resample_tokens(src, src_f32, Dp, m->has_cls, g, out, ldo, out_grid, idx0, idx1, frac, B, D, dt, stream);
+    return tdc_resample_tokens(src, src_f32, Dp, m->has_cls, g, out, ldo, out_grid, idx0, idx1, frac, B, D, dt, m->out_dtype,
+                               stream);
 }
 
 // ---- connector (a6-a9) -------------------------------------------------------------------------------------------------

@@ -10,9 +10,14 @@ namespace {
 // ------------------------------------------------------------------------------------------------ im2col
 // patches[(b*gh+gy)*gw+gx][c*p*p + ky*p + kx] = px[b][c][gy*p+ky][gx*p+kx]; one workgroup per patch row (b,gy):
 // reads are contiguous along W, writes contiguous along the patch vector.
+template <class T> struct Other16;
+template <> struct Other16<f16> { typedef bf16 type; };
+template <> struct Other16<bf16> { typedef f16 type; };
+// px_f32: 0 = pixels of type T, 1 = fp32, 2 = the other 16-bit type (fp16 frames into bf16 towers and vice versa)
 template <class T>
 __global__ __launch_bounds__(256) void im2col_kernel(const void* px, int px_f32, T* out, int ldp, int H, int W,
                                                      int patch, int gh, int gw) {
+    typedef typename Other16<T>::type TX;
     const int b = blockIdx.y, gy = blockIdx.x;
     const int kdim = 3 * patch * patch;
     const long long img = (long long)b * 3 * H * W;
@@ -23,7 +28,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const void* px, int px_f32,
             int c = k / (patch * patch), rem = k - c * patch * patch;
             int ky = rem / patch, kx = rem - ky * patch;
             long long src = img + ((long long)c * H + gy * patch + ky) * W + gx * patch + kx;
-            v = px_f32 ? ((const float*)px)[src] : (float)((const T*)px)[src];
+            v = px_f32 == 1 ? ((const float*)px)[src] : px_f32 == 2 ? (float)((const TX*)px)[src] : (float)((const T*)px)[src];
         }
         out[((long long)(b * gh + gy) * gw + gx) * ldp + k] = (T)v;
     }
@@ -35,9 +40,10 @@ __global__ void set_rows_kernel(float* x, int ld, int S, int row, const float* v
 }
 
 // ------------------------------------------------------------------------------------------------ resample
-template <class T>
+template <class T, class TO>   // T: 16-bit type of x (when !x_f32), TO: 16-bit type of y (they differ when the towers run in
+                               // bf16 and the connector behind them in fp16)
 __global__ __launch_bounds__(256) void resample_kernel(const void* x, int x_f32, int ldx, int tok_off, int n_in,
-                                                       T* y, int ldy, int n_out, const int* i0, const int* i1,
+                                                       TO* y, int ldy, int n_out, const int* i0, const int* i1,
                                                        const float* fr, int cols) {
     // F.interpolate(bilinear) is separable; torch evaluates w00*a + w01*b + w10*c + w11*d per output pixel
     const int b = blockIdx.y, o = blockIdx.x;
@@ -47,7 +53,7 @@ __global__ __launch_bounds__(256) void resample_kernel(const void* x, int x_f32,
     const long long base = (long long)b * (tok_off + n_in * n_in) + tok_off;
     const long long r00 = (base + y0 * n_in + x0) * ldx, r01 = (base + y0 * n_in + x1) * ldx;
     const long long r10 = (base + y1 * n_in + x0) * ldx, r11 = (base + y1 * n_in + x1) * ldx;
-    T* out = y + ((long long)b * n_out * n_out + o) * ldy;
+    TO* out = y + ((long long)b * n_out * n_out + o) * ldy;
     for (int c = threadIdx.x; c < ldy; c += 256) {
         float v = 0.f;
         if (c < cols) {
@@ -61,7 +67,7 @@ __global__ __launch_bounds__(256) void resample_kernel(const void* x, int x_f32,
             }
             v = (1.f - fy) * ((1.f - fx) * a + fx * bb) + fy * ((1.f - fx) * cc + fx * d);
         }
-        out[c] = (T)v;
+        out[c] = (TO)v;
     }
 }
 
@@ -271,7 +277,7 @@ __global__ __launch_bounds__(256) void sva_kernel(SvaArgs p) {
 
 extern "C" int tdc_im2col(const void* px, int px_f32, void* patches, int ldp, int B, int H, int W, int patch,
                           int dtype, void* stream) {
-    if (!px || !patches || B <= 0 || patch <= 0 || ldp < 3 * patch * patch) return TDC_E_BADARG;
+    if (!px || !patches || B <= 0 || patch <= 0 || ldp < 3 * patch * patch || px_f32 < 0 || px_f32 > 2) return TDC_E_BADARG;
     const int gh = H / patch, gw = W / patch;
     hipStream_t st = (hipStream_t)stream;
     DISPATCH(dtype, hipLaunchKernelGGL(im2col_kernel<TT>, dim3(gh, B), dim3(256), 0, st, px, px_f32, (TT*)patches,
@@ -287,11 +293,16 @@ extern "C" int tdc_set_rows(float* x32, int ld, int B, int S, int row, const flo
 
 extern "C" int tdc_resample_tokens(const void* x, int x_f32, int ldx, int tok_off, int n_in, void* y, int ldy,
                                    int n_out, const int* idx0, const int* idx1, const float* frac, int B, int cols,
-                                   int dtype, void* stream) {
+                                   int dtype, int out_dtype, void* stream) {
     if (!x || !y || !idx0 || !idx1 || !frac || B <= 0) return TDC_E_BADARG;
+    if ((dtype != TDC_F16 && dtype != TDC_BF16) || (out_dtype != TDC_F16 && out_dtype != TDC_BF16)) return TDC_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH(dtype, hipLaunchKernelGGL(resample_kernel<TT>, dim3(n_out * n_out, B), dim3(256), 0, st, x, x_f32, ldx,
-                                       tok_off, n_in, (TT*)y, ldy, n_out, idx0, idx1, frac, cols));
+    const dim3 grid(n_out * n_out, B);
+#define RESAMPLE(TI, TO_) hipLaunchKernelGGL((resample_kernel<TI, TO_>), grid, dim3(256), 0, st, x, x_f32, ldx, tok_off, \
+                                             n_in, (TO_*)y, ldy, n_out, idx0, idx1, frac, cols)
+    if (dtype == TDC_F16) { if (out_dtype == TDC_F16) RESAMPLE(f16, f16); else RESAMPLE(f16, bf16); }
+    else { if (out_dtype == TDC_F16) RESAMPLE(bf16, f16); else RESAMPLE(bf16, bf16); }
+#undef RESAMPLE
     return (int)hipGetLastError();
 }
 

@@ -84,7 +84,7 @@ class VitModel(C.Structure):
                 ("n_layers", C.c_int), ("patch", C.c_int), ("has_cls", C.c_int), ("act", C.c_int),
                 ("eps", C.c_float), ("patch_lin", Lin), ("pos", C.c_void_p), ("ldpos", C.c_int),
                 ("cls_row", C.c_void_p), ("lnf_g", C.c_void_p), ("lnf_b", C.c_void_p),
-                ("layers_host", C.POINTER(VitLayer)), ("fused", C.c_int), ("fp8", C.c_int)]
+                ("layers_host", C.POINTER(VitLayer)), ("fused", C.c_int), ("fp8", C.c_int), ("out_dtype", C.c_int)]
 
 
 class AuxProj(C.Structure):
@@ -133,7 +133,7 @@ SIGNATURES = {
                              C.c_void_p]),
     "tdc_set_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "tdc_resample_tokens": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
-                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "tdc_frame_cossim": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "tdc_frame_cossim_scratch_floats": (C.c_size_t, [C.c_int]),
     "tdc_token_mean": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -181,7 +181,11 @@ def _build_once():
     (file lock; the losers find the finished .so).  Never rebuilds an existing library - staleness is build.py's business."""
     import fcntl
     import importlib.util
-    lock = open(os.path.join(HERE, ".build.lock"), "w")
+    try:
+        lock = open(os.path.join(HERE, ".build.lock"), "w")
+    except OSError as e:      # read-only install: nothing can be built here
+        raise TdcHipError("libtdc_hip.so is missing and %s is not writable (%s): build it with `python -c 'import "
+                          "__graft_entry__ as g; g.build()'` in a writable checkout" % (HERE, e))
     try:
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not os.path.exists(LIB_PATH):

@@ -350,7 +350,9 @@ class CambrianMetaModel:
     def tdc_engine(self, device=None, dtype=None, refresh=False):
         """Build (once) the VideoEncoder from the current parameters: pads / fuses / uploads the weights.
         `config.tdc_fp8_towers = True` / 2 / 3 (not a reference key) selects e4m3 operands for the towers' qkv / fc1 GEMMs
-        (2: out-proj / fc2 as well; 3: fc1 also writes the e4m3 MLP hidden itself)."""
+        (2: out-proj / fc2 as well; 3: fc1 also writes the e4m3 MLP hidden itself; DESIGN.md §4c);
+        `config.tdc_tower_dtype = "bfloat16" | "float16"` (not a reference key either) runs the two ViT towers in that type
+        under a connector / Q-Former in `dtype` (VideoEncoder.tower_dtype)."""
         if self._tdc_encoder is None or refresh:
             cfg = {k: getattr(self.config, k) for k in dir(self.config)
                    if not k.startswith("_") and isinstance(getattr(self.config, k, None), (int, float, str, bool, list))}
@@ -360,7 +362,10 @@ class CambrianMetaModel:
             self._tdc_encoder = VideoEncoder(self.tdc_state_dict(), cfg, dtype=dtype, device=device,
                                              siglip_heads=towers[0].heads, dino_heads=towers[1].heads,
                                              qformer_heads=self._qformer_arch["heads"],
-                                             fp8_towers=int(cfg.get("tdc_fp8_towers", 0) or 0))
+                                             fp8_towers=int(cfg.get("tdc_fp8_towers", 0) or 0),
+                                             tower_dtype={"bfloat16": torch.bfloat16, "bf16": torch.bfloat16,
+                                                          "float16": torch.float16, "fp16": torch.float16,
+                                                          None: None}[cfg.get("tdc_tower_dtype")])
         return self._tdc_encoder
 
 

@@ -266,14 +266,21 @@ def attention(q, k, v, out, batch, heads, head_dim, sq, sk, scale, q_bs, k_bs, v
     return out
 
 
+def px_kind(px, dtype):
+    """the px_f32 argument of tdc_im2col / tdc_vit_fwd: 0 = pixels of the towers' 16-bit type, 1 = fp32, 2 = the other one"""
+    if px.dtype == torch.float32:
+        return 1
+    assert px.dtype in (torch.float16, torch.bfloat16) and dtype in (torch.float16, torch.bfloat16)
+    return 0 if px.dtype == dtype else 2
+
+
 def im2col(px, patch, dtype):
     B, Cc, H, W = px.shape
     assert Cc == 3 and px.is_contiguous() and px.is_cuda
     gh, gw = H // patch, W // patch
     ldp = pad64(3 * patch * patch)
     out = torch.empty(B * gh * gw, ldp, device=px.device, dtype=dtype)
-    f32 = int(px.dtype == torch.float32)
-    assert f32 or px.dtype == dtype
+    f32 = px_kind(px, dtype)
     L.check(L.load().tdc_im2col(_ptr(px), f32, _ptr(out), ldp, B, H, W, patch, _dtcode(dtype), _stream()),
             "tdc_im2col")
     return out, gh, gw
@@ -298,15 +305,18 @@ def bilinear_tables(n_in, n_out, device):
             torch.tensor(fr, dtype=torch.float32, device=device))
 
 
-def resample_tokens(x, B, tok_off, n_in, n_out, cols, dtype, tables):
+def resample_tokens(x, B, tok_off, n_in, n_out, cols, dtype, tables, out_dtype=None):
+    """dtype: 16-bit type of x (when x is not fp32); out_dtype: 16-bit type of the result (default: dtype)."""
     _chk2d(x, "x")
     assert x.shape[0] >= B * (tok_off + n_in * n_in) and x.shape[1] >= cols
     ldy = pad64(cols)
-    y = torch.empty(B * n_out * n_out, ldy, device=x.device, dtype=dtype)
+    out_dtype = dtype if out_dtype is None else out_dtype
+    y = torch.empty(B * n_out * n_out, ldy, device=x.device, dtype=out_dtype)
     i0, i1, fr = tables
     assert i0.numel() == n_out and int(i1.max()) < n_in
     L.check(L.load().tdc_resample_tokens(_ptr(x), int(x.dtype == torch.float32), x.stride(0), tok_off, n_in, _ptr(y),
-                                         ldy, n_out, _ptr(i0), _ptr(i1), _ptr(fr), B, cols, _dtcode(dtype), _stream()),
+                                         ldy, n_out, _ptr(i0), _ptr(i1), _ptr(fr), B, cols, _dtcode(dtype),
+                                         _dtcode(out_dtype), _stream()),
             "tdc_resample_tokens")
     return y
 

@@ -20,21 +20,26 @@ from .weights import pad64
 
 class VideoEncoder:
     def __init__(self, sd, cfg, dtype=torch.float16, device="cuda", siglip_heads=16, dino_heads=24,
-                 qformer_heads=12, tower_batch=64, fp8_towers=False):
+                 qformer_heads=12, tower_batch=64, fp8_towers=False, tower_dtype=None):
         """sd: reference-named state dict without the leading 'model.'; cfg: dict of reference config keys.
+        dtype: 16-bit type of the connector, the Q-Former and every tensor handed to the caller; tower_dtype (default:
+        dtype): 16-bit type of the two ViT towers - their last kernel (the token-grid resample) writes `dtype` rows.  bf16
+        towers under an fp16 connector / compressor keep the compressed tokens within 1e-3 of the fp32 reference arithmetic (measured
+        1.0e-4 at full depth; all-bf16: 6e-4 ... 2e-3): the 16-bit error of the context tokens is made behind the towers.
         fp8_towers (BASELINE config 5): the towers' LayerNorms emit e4m3 rows with per-row scales and the qkv / fc1 GEMMs
-        run on fp8 operands (v_mfma_f32_16x16x128_f8f6f4); everything else stays in `dtype`."""
+        run on fp8 operands (v_mfma_f32_16x16x128_f8f6f4); everything else stays in `tower_dtype`."""
         self.cfg = dict(cfg)
         self.dtype, self.dev = dtype, torch.device(device)
+        self._tower_dtype = tower_dtype = dtype if tower_dtype is None else tower_dtype
         self.tower_batch = tower_batch
         self.qheads = qformer_heads
         s_sd = Wt._strip(sd, "vision_tower_aux_list.0.vision_tower.")
         d_sd = Wt._strip(sd, "vision_tower_aux_list.1.vision_tower.")
         self.towers = {}
         if s_sd:
-            self.towers["siglip"] = Wt.prep_siglip(s_sd, siglip_heads, dtype, self.dev, fp8=fp8_towers)
+            self.towers["siglip"] = Wt.prep_siglip(s_sd, siglip_heads, tower_dtype, self.dev, fp8=fp8_towers)
         if d_sd:
-            self.towers["dino"] = Wt.prep_dino(d_sd, dino_heads, dtype, self.dev, fp8=fp8_towers)
+            self.towers["dino"] = Wt.prep_dino(d_sd, dino_heads, tower_dtype, self.dev, fp8=fp8_towers)
         self.c = Wt.prep_connector(sd, cfg, dtype, self.dev)
         tok = cfg.get("mm_vision_tower_aux_token_len_list", [576, 576])
         self.out_grid = [int(round(t ** 0.5)) for t in tok]
@@ -47,6 +52,10 @@ class VideoEncoder:
         self.native_towers = True     # towers through the C++ composite tdc_vit_fwd (per-kernel Python path when False)
         self.beats = None             # beats.BeatsEncoder for raw-waveform audio input
 
+    @property
+    def tower_dtype(self):
+        return self.__dict__.get("_tower_dtype") or self.dtype
+
     # ------------------------------------------------------------------------------------------------ towers
     def _bil(self, n_in, n_out):
         key = (n_in, n_out)
@@ -55,7 +64,7 @@ class VideoEncoder:
         return self._tables[key]
 
     def tower(self, name, px):
-        """px [B,3,H,W] (fp32 or compute dtype) -> features [B*g*g, pad64(D)] 16-bit (g = 24)."""
+        """px [B,3,H,W] (fp32, fp16 or bf16) -> features [B*g*g, pad64(D)] 16-bit `dtype` (g = 24)."""
         t = self.towers[name]
         out_grid = self.out_grid[0 if name == "siglip" else 1]
         outs = []
@@ -88,7 +97,7 @@ class VideoEncoder:
                                    zeros.data_ptr() if zeros is not None else None,
                                    Lr.out.wscale or 0.0, Lr.fc2.wscale or 0.0, Lr.fc1.w2max, Lr.fc1.bmax)
         m = L.VitModel()
-        m.dtype = ops._dtcode(self.dtype)
+        m.dtype, m.out_dtype = ops._dtcode(self.tower_dtype), ops._dtcode(self.dtype)
         m.dim, m.heads, m.head_dim, m.n_layers, m.patch, m.has_cls = t.dim, t.heads, t.head_dim, len(t.layers), t.patch, \
             t.has_cls
         m.act = {"gelu_tanh": L.ACT_GELU_TANH, "gelu_erf": L.ACT_GELU_ERF, "swiglu": L.ACT_SWIGLU}[t.act]
@@ -121,8 +130,7 @@ class VideoEncoder:
         D = t.dim
         out = torch.empty(B * out_grid * out_grid, pad64(D), device=self.dev, dtype=self.dtype)
         i0, i1, fr = self._bil(g, out_grid)
-        f32 = int(px.dtype == torch.float32)
-        assert f32 or px.dtype == self.dtype
+        f32 = ops.px_kind(px, self.tower_dtype)
         L.check(lib.tdc_vit_fwd(C.byref(m), ops._ptr(px), f32, B, H, W, out_grid, ops._ptr(i0), ops._ptr(i1),
                                 ops._ptr(fr), ops._ptr(out), out.stride(0), ops._ptr(ws), ws.numel(), ops._stream()),
                 "tdc_vit_fwd")
@@ -131,7 +139,7 @@ class VideoEncoder:
     def _tower_batch(self, t, px, out_grid):
         if getattr(self, "native_towers", True) and ops.PROFILE is None and len(t.layers) > 0:
             return self._tower_batch_native(t, px, out_grid)
-        dt, dev = self.dtype, self.dev
+        dt, dev = self.tower_dtype, self.dev
         B = px.shape[0]
         D, Dp = t.dim, pad64(t.dim)
         patches, gh, gw = ops.im2col(px, t.patch, dt)
@@ -217,7 +225,7 @@ class VideoEncoder:
         if t.get("final_ln"):
             ops.layernorm(x32, t.final_ln[0], t.final_ln[1], t.eps, D, dt, y16=h16)
             src = h16
-        return ops.resample_tokens(src, B, t.has_cls, gh, out_grid, D, dt, self._bil(gh, out_grid))
+        return ops.resample_tokens(src, B, t.has_cls, gh, out_grid, D, dt, self._bil(gh, out_grid), out_dtype=self.dtype)
 
     # ------------------------------------------------------------------------------------------------ a5
     def sims_tensor(self, dino_feat, T):

@@ -141,13 +141,16 @@ def build_lm(cfg, seed=0):
                     p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
                 elif name.endswith("bias"):
                     p.copy_(0.1 * torch.randn(p.shape, generator=g))
-        for tower in m.vision_tower_aux_list:
+        # DINOv2's HF init (trunc-normal, std 0.02) leaves a 64-wide block close to the identity: x3 gives its attention and
+        # MLP something to do.  SigLIP's lecun-normal init (std 1/sqrt(fan_in)) is already at its natural scale and stays as
+        # it is (round 2 scaled it x3 too: activations ~60 and a 6x looser bound on every SigLIP-bearing stage).
+        for ti, tower in enumerate(m.vision_tower_aux_list):
             for name, p in tower.vision_tower.named_parameters():
                 if p.ndim == 1 and (name.endswith("weight") or "lambda1" in name):
                     p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
                 elif p.ndim == 1:
                     p.copy_(0.1 * torch.randn(p.shape, generator=g))
-                elif p.ndim == 2 and "position" not in name:
+                elif p.ndim == 2 and "position" not in name and ti == 1:
                     p.copy_(p * 3.0)
         m.image_newline.copy_(torch.randn(m.image_newline.shape, generator=g))
         m.embed_tokens.weight.copy_(0.5 * torch.randn(m.embed_tokens.weight.shape, generator=g))
@@ -368,8 +371,8 @@ def make_towers():
                     p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
                 elif p.ndim == 1:
                     p.copy_(0.1 * torch.randn(p.shape, generator=g))
-                elif p.ndim == 2 and "position" not in n:
-                    p.copy_(p * 3.0)
+                elif p.ndim == 2 and "position" not in n and mod is dino:
+                    p.copy_(p * 3.0)           # SigLIP keeps its natural (lecun-normal) scale, see build_lm
     px = torch.rand(3, 3, 126, 126, generator=g) * 2 - 1
     with torch.no_grad():
         so = sig(px)

@@ -105,6 +105,65 @@ def test_config1_8frames_336px_end_to_end_vs_oracle(mns, expect_qformer):
         assert err < 1e-3, err
 
 
+@pytest.mark.parametrize("tower_dtype", [torch.float16, torch.bfloat16])
+def test_config1_full_depth_end_to_end_vs_oracle(tower_dtype):
+    """BASELINE config 1 with NOTHING cut: 8 frames at 336 px, pixels -> 27-layer SigLIP / 40-layer DINOv2 -> connector ->
+    Q-Former (K = 144, max_num_segments = 2 so that the 8 frames are segmented and compressed) -> emitted tokens, fp16 (the
+    reference's inference dtype, tdc/builder.py:69), against oracle.encode_video (cambrian_arch.py:946-966,1653-1667).
+    Checked: segment / frame selection bit-exact; the adjacent-frame similarities of the 40-layer DINOv2 features and the
+    margin between the ranks that decide the selection; static rows <= 4e-3 of max|ref|; compressed (unit-norm) tokens
+    <= 1e-3 abs - the north_star's tolerance, here through the whole composition rather than stage by stage.
+    tower_dtype = bfloat16 is the bench's type (bf16 towers under an fp16 connector / Q-Former, VideoEncoder.tower_dtype):
+    the same 1e-3 on the compressed tokens; the tower features themselves carry the bf16 error (6e-2 of max|ref| allowed)."""
+    import bench
+    import tdc_video_amd  # noqa: F401
+    from tdc_video_amd.pipeline import VideoEncoder
+    orc = _oracle()
+    H, K, T, px, mns = 3584, 144, 8, 336, 2
+    sd = {k: v.float().cpu() for k, v in _sd(H, K, px).items()}
+    cfg = bench.model_cfg(H, K, T)
+    cfg.update(max_num_segments=mns, siglip_heads=16, dino_heads=24, qformer_heads=12)
+    enc = VideoEncoder(sd, cfg, dtype=torch.float16, tower_dtype=tower_dtype, device="cuda:0", siglip_heads=16, dino_heads=24,
+                       qformer_heads=12)
+    assert len(enc.towers["siglip"].layers) == 27 and len(enc.towers["dino"].layers) == 40
+    tol_tower = 4e-3 if tower_dtype == torch.float16 else 6e-2
+    vs = bench.synth_video(0, T, px, "cuda:0", torch.float16, scene_len=3)
+    vd = bench.synth_video(0, T, px, "cuda:0", torch.float16, seed=4321, scene_len=3)
+    ids = torch.tensor([[1, 2, 3, -200, 4, 5]])
+    keep = {}
+    got = enc.encode_video(vs, vd, (336, 336), budget_text_len=ids.shape[1], n_text_tokens=ids.shape[1] - 1,
+                           prompt_ids=PROMPT, keep=keep)
+    sims_hip = enc.sims_tensor(keep["dino_feat"], T).cpu()
+    W = dict(sd)
+    W["embed_tokens_fn"] = _embed_fn(H)
+    with torch.no_grad():
+        r = orc.encode_video(W, cfg, vs.float().cpu(), vd.float().cpu(), (336, 336), ids, torch.tensor(PROMPT))
+        sims_ref = orc.adjacent_cosine(r["dino_feat"])
+    # a5 at 40 layers: the similarities themselves and the margin of the ranking that selects the boundaries
+    sim_err = float((sims_hip - sims_ref).abs().max())
+    srt = torch.sort(sims_ref)[0]
+    margin = float(srt[mns] - srt[mns - 1])
+    es = _rel(keep["siglip_feat"][:, :1152].reshape(T, 576, 1152), r["siglip_feat"])
+    ed = _rel(keep["dino_feat"][:, :1536].reshape(T, 576, 1536), r["dino_feat"])
+    plan = keep["plan"]
+    comp_rows = [i for i, e in enumerate(plan["src"]) if e[0] == "c"]
+    stat_rows = [i for i, e in enumerate(plan["src"]) if e[0] != "c"]
+    want = r["visual_tokens"]
+    assert tuple(got.shape) == tuple(want.shape)
+    e_stat = _rel(got[stat_rows], want[stat_rows])
+    e_comp = float((got[comp_rows].float().cpu() - want[comp_rows]).abs().max())
+    print("config 1 full depth, towers %s / rest fp16: towers siglip %.3e dino %.3e (of max|ref|); similarities max abs err %.3e, ranking "
+          "margin %.3e; static rows %.3e; compressed tokens max abs err %.3e" % (tower_dtype, es, ed, sim_err, margin, e_stat,
+                                                                                 e_comp))
+    assert keep["seg_indices"] == [int(i) for i in r["seg_indices"]] == [2, 5]
+    assert keep["selected"] == [int(i) for i in r["selected"]]
+    assert [list(s) for s in keep["final_size"]] == [list(s) for s in r["final_size"]]
+    assert sim_err < (1e-4 if tower_dtype == torch.float16 else 2e-3) and sim_err < 0.01 * margin, (sim_err, margin)
+    assert es < tol_tower and ed < tol_tower, (es, ed)
+    assert len(comp_rows) > 0 and e_stat < 4e-3, e_stat
+    assert e_comp < 1e-3, e_comp
+
+
 # ------------------------------------------------------------------------------------------------------------ config 2
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 8e-3), (torch.bfloat16, 6e-2)])
 def test_config2_336px_towers_full_depth_vs_oracle(dtype, tol):

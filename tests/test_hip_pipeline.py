@@ -25,20 +25,26 @@ def rel(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item()
 
 
+MIXED = "bf16 towers + fp16"     # the bench's type: towers in bf16, connector / Q-Former in fp16 (VideoEncoder.tower_dtype)
+
+
 def stage_tol(dtype, key=""):
-    """max|err| / max|ref|.  The fixtures' SigLIP tower has its matrices scaled x3 (activations up to ~60, peaky
-    attention), which amplifies 16-bit rounding ~10x on `siglip_feat` and its projection `aux0` (measured:
-    fp16 6e-3..1.3e-2, bf16 4e-2..1.5e-1; every other stage fp16 <= 1.1e-3, bf16 <= 8e-3);
-    test_towers_natural_scale covers the same code at trained-model-like scales with the tight bound."""
-    loose = key in ("siglip_feat", "aux0", "siglip_small.npz")
-    if dtype == torch.float16:
-        return 2.5e-2 if loose else 4e-3
-    return 2.5e-1 if loose else 3e-2
+    """max|err| / max|ref| of a stage output, every fixture and stage alike (measured: fp16 <= 1.1e-3, bf16 <= 8e-3).  The
+    mixed type inherits the bf16 towers' error in every stage behind them."""
+    return 4e-3 if dtype == torch.float16 else 3e-2
+
+
+def comp_tol(dtype):
+    """compressed (unit-norm) context tokens, absolute: the north_star's 1e-3 for fp16 AND for the bench's mixed type"""
+    return 8e-3 if dtype == torch.bfloat16 else 1e-3
 
 
 def make_encoder(W, cfg, dtype):
     import tdc_video_amd  # noqa: F401
     from tdc_video_amd.pipeline import VideoEncoder
+    if dtype == MIXED:
+        return VideoEncoder(W, cfg, dtype=torch.float16, tower_dtype=torch.bfloat16, device="cuda", siglip_heads=4,
+                            dino_heads=4, qformer_heads=4)
     return VideoEncoder(W, cfg, dtype=dtype, device="cuda", siglip_heads=4, dino_heads=4, qformer_heads=4)
 
 
@@ -219,7 +225,7 @@ def test_qformer_chunk_vs_golden(dtype):
     assert torch.equal(vis[N + 1:N + 1 + K].cpu(), keep["compressed"][:K, :H].cpu())
 
 
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, MIXED])
 @pytest.mark.parametrize("name", ["pipeline_T40.npz", "pipeline_T10_land.npz", "pipeline_T260.npz"])
 def test_full_pipeline_vs_golden(name, dtype):
     W, o = load_fixture(name)
@@ -269,10 +275,11 @@ def test_full_pipeline_vs_golden(name, dtype):
         got = torch.stack([comp[a * 4 + b] for (a, b) in ref_rows])
         want = torch.stack(list(ref_rows.values()))
         err = (got - want).abs().max().item()
-        assert err < (1e-3 if dtype == torch.float16 else 8e-3), err
+        print("%s %s: compressed-token max abs err %.3e" % (name, dtype, err))
+        assert err < comp_tol(dtype), err
 
 
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, MIXED])
 @pytest.mark.parametrize("name", ["pipeline_T40_nostatic.npz", "pipeline_T40_learned.npz"])
 def test_config_ablations_vs_golden(name, dtype):
     """add_static=False / query_type='learned' (reference-generated fixtures): emitted stream vs the reference's."""
