@@ -72,6 +72,11 @@ typedef struct {
      * an order of magnitude loose costs no relative precision.  out_stats[m] = (0, s_h[m] * out_wscale) are the ln_stats
      * of the fp8-operand GEMM that consumes C (out_wscale = its per-tensor weight scale). */
     int out_fp8; float* out_stats; float out_w2max, out_bmax, out_wscale;
+    /* c_pad8 != 0 (16-bit C, no residual, no bias, N % 4 == 0, ldc >= round_up(N, 8)): the rows of C are writable up to
+     * round_up(N, 8) columns - the 16-byte row stores of the staged epilogue may then run 4 columns past an N with
+     * N % 8 == 4 (unspecified values there) instead of falling back to 8-byte stores.  Used by the transposed value
+     * projection of the Q-Former (N = frames x tokens). */
+    int c_pad8;
 } tdc_gemm_desc;
 int tdc_gemm(const tdc_gemm_desc* d, void* stream);
 /* Diagnostics only (tools/, never the product path): 1 = skip the C-tile epilogue (nothing is written), 2 = un-staged
@@ -253,6 +258,8 @@ typedef struct {
     tdc_lin cross_q, cross_out; const float *cross_ln_g, *cross_ln_b;
     tdc_lin fq1, fq2; const float *fq_ln_g, *fq_ln_b;      /* intermediate_query / output_query */
     tdc_lin ft1, ft2; const float *ft_ln_g, *ft_ln_b;      /* intermediate / output (text rows) */
+    const void *cross_q_tiled, *cross_out_tiled;           /* fragment-major copies of cross_q.w / cross_out.w for the fused block
+                                                              (tdc_qformer_xattn_tile_weight), NULL: the per-kernel sequence */
 } tdc_qformer_layer;
 typedef struct {
     int dtype, dim, heads, n_layers, H;
@@ -262,8 +269,39 @@ typedef struct {
     tdc_lin cross_kv;                                       /* [n_cross*2*dim, pad64(H)]: (K_j | V_j) per cross layer */
     tdc_lin vision_proj;                                    /* [pad64(H), pad64(dim)] */
     const tdc_qformer_layer* layers_host;
+    /* the fused cross-attention block (tdc_qformer_xattn; used when tdc_qformer_xattn_supported() and cross_k.w != NULL):
+     * the same projections stacked per kind - cross_k [n_cross*dim, pad64(H)] with its bias, cross_v [n_cross*dim, pad64(H)]
+     * WITHOUT bias (it is the A operand of the transposed GEMM V^T = Wv enc^T) and cross_bv [n_cross*dim] fp32 = the value
+     * biases, added after the PV product */
+    tdc_lin cross_k, cross_v; const float* cross_bv;
 } tdc_qformer_model;
 size_t tdc_qformer_workspace_bytes(const tdc_qformer_model* m, int F, int K, int Lt, int Nenc);
+
+/* ---- the Q-Former cross-attention block of one layer as ONE kernel (the north_star's kernel) ----------
+ * Replaces, for the K query rows of every compressed frame, BertSelfAttention (cross form) + BertSelfOutput
+ * (tdc/Qformer.py:128-130,185-188,205-264,285-289, called from BertLayer.forward :432-447):
+ *     q = h[:, :K] Wq^T + bq;  ctx = softmax(q_h k_h^T * scale) v_h per head;  h[:, :K] = LayerNorm(ctx Wo^T + bo + h[:, :K])
+ * h16 / h32: the 16-bit copy and the fp32 master of the hidden stream [F*S, ldh] (query rows of frame f = rows f*S + [0, K));
+ * both are updated in place.  k [F*Nenc, ldk]: this layer's key rows (enc Wk^T + bk; pass the column-offset pointer);
+ * vt [dim, ldvt]: this layer's values TRANSPOSED, vt[c][f*Nenc + key] = (enc Wv^T)[f*Nenc + key][c] WITHOUT the bias -
+ * i.e. tdc_gemm with A = Wv, W = enc -; bv [dim] fp32 or NULL.  wq / wo: the two [dim, dim] weights in the kernel's
+ * FRAGMENT-MAJOR layout, dim*dim 16-bit values each, made once per weight by tdc_qformer_xattn_tile_weight from the
+ * nn.Linear layout [dim, ldw] (a wave's MFMA operand is then 1 KiB of consecutive bytes instead of 16 rows x 64 B).
+ * Supported: dim == 768, head dim 64, K % 16 == 0, Nenc % 4 == 0, 8 <= Nenc <= 224 (tdc_qformer_xattn_supported); the
+ * composite tdc_qformer_fwd falls back to the per-kernel sequence (q GEMM, tdc_attention, dense GEMM, tdc_layernorm) otherwise. */
+typedef struct {
+    void* h16; float* h32; int ldh;
+    int F, K, S;
+    const void* wq; const float* bq; const void* wo; const float* bo;
+    const void* k; int ldk;
+    const void* vt; long long ldvt; const float* bv;
+    int Nenc;
+    const float *ln_g, *ln_b; float eps;
+    int dim, heads; float scale; int dtype;
+} tdc_xattn_desc;
+int tdc_qformer_xattn_supported(int dim, int heads, int K, int Nenc);
+int tdc_qformer_xattn(const tdc_xattn_desc* d, void* stream);
+int tdc_qformer_xattn_tile_weight(const void* w, int ldw, void* out, int dtype, void* stream);
 int tdc_qformer_fwd(const tdc_qformer_model* m, const void* enc, int ldenc, int F, int Nenc, const void* query, int ldq,
                     const int* qsrc, const int* ids, int Lt, int K, void* out, int ldo, void* workspace,
                     size_t workspace_bytes, void* stream);

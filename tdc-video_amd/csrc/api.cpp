@@ -122,8 +122,16 @@ int layernorm(const float* x, int ldx, void* y16, int ldy, const float* g, const
 }
 
 struct QfWs {
-    size_t h32, h16, kv, qkv, ctx, ctxq, cq, t32, t32b, mq, mt, total;
+    size_t h32, h16, kv, vt, ldvt, qkv, ctx, ctxq, cq, t32, t32b, mq, mt, total;
 };
+
+// the fused cross-attention block (tdc_qformer_xattn) runs when its weights are given and the shape is one it supports
+bool qf_fused(const tdc_qformer_model* m, int K, int Nenc) {
+    for (int l = 0; l < m->n_layers; ++l)
+        if (m->layers_host[l].has_cross && (!m->layers_host[l].cross_q_tiled || !m->layers_host[l].cross_out_tiled)) return false;
+    return m->cross_k.w && m->cross_v.w && m->cross_k.n == m->cross_v.n && m->cross_k.k == m->cross_v.k &&
+           tdc_qformer_xattn_supported(m->dim, m->heads, K, Nenc);
+}
 
 QfWs qf_layout(const tdc_qformer_model* m, int F, int K, int Lt, int Nenc) {
     const size_t S = (size_t)K + Lt, rows = (size_t)F * S, Dp = pad64i(m->dim);
@@ -132,7 +140,14 @@ QfWs qf_layout(const tdc_qformer_model* m, int F, int K, int Lt, int Nenc) {
     size_t off = 0;
     w.h32 = off;  off += al256(rows * Dp * 4);
     w.h16 = off;  off += al256(rows * Dp * 2);
-    w.kv = off;   off += al256((size_t)F * Nenc * m->cross_kv.n * 2);
+    w.vt = 0; w.ldvt = 0;
+    if (qf_fused(m, K, Nenc)) {     // keys [F*Nenc, n_cross*dim] and transposed values [n_cross*dim, ldvt]
+        w.ldvt = ((size_t)F * Nenc + 63) / 64 * 64;
+        w.kv = off;   off += al256((size_t)F * Nenc * m->cross_k.n * 2);
+        w.vt = off;   off += al256((size_t)m->cross_v.n * w.ldvt * 2);
+    } else {
+        w.kv = off;   off += al256((size_t)F * Nenc * m->cross_kv.n * 2);
+    }
     w.qkv = off;  off += al256(rows * m->layers_host[0].qkv.n * 2);
     w.ctx = off;  off += al256(rows * Dp * 2);
     w.ctxq = off; off += al256((size_t)F * K * Dp * 2);
@@ -208,8 +223,21 @@ extern "C" int tdc_qformer_fwd(const tdc_qformer_model* m, const void* enc, int 
         e.F = F; e.K = K; e.cols = D; e.dtype = dt;
         RET_IF(tdc_qformer_embed(&e, stream));
     }
-    RET_IF(gemm_full(enc, ldenc, m->cross_kv, kv, m->cross_kv.n, F * Nenc, dt, TDC_ACT_NONE, 0, nullptr, 0, 0, ident,
-                     ident, ident, stream));
+    const bool fused = qf_fused(m, K, Nenc);
+    if (fused) {
+        // keys of all cross layers: one GEMM; values of all cross layers TRANSPOSED: one GEMM with the operands swapped
+        // (A = Wv [n_cross*dim, H], "weight" = enc [F*Nenc, H]) - vt[c][f*Nenc + key], the A operand of the PV product
+        RET_IF(gemm_full(enc, ldenc, m->cross_k, kv, m->cross_k.n, F * Nenc, dt, TDC_ACT_NONE, 0, nullptr, 0, 0, ident,
+                         ident, ident, stream));
+        tdc_gemm_desc d;
+        memset(&d, 0, sizeof(d));
+        d.A = m->cross_v.w; d.lda = m->cross_v.k; d.W = enc; d.ldw = ldenc; d.C = ws + w.vt; d.ldc = (int)w.ldvt;
+        d.M = m->cross_v.n; d.N = F * Nenc; d.K = m->cross_v.k; d.dtype = dt; d.c_pad8 = 1;
+        RET_IF(tdc_gemm(&d, stream));
+    } else {
+        RET_IF(gemm_full(enc, ldenc, m->cross_kv, kv, m->cross_kv.n, F * Nenc, dt, TDC_ACT_NONE, 0, nullptr, 0, 0, ident,
+                         ident, ident, stream));
+    }
     const float scale = 1.0f / sqrtf((float)hd);
     for (int l = 0; l < m->n_layers; ++l) {
         const tdc_qformer_layer& L = m->layers_host[l];
@@ -225,7 +253,18 @@ extern "C" int tdc_qformer_fwd(const tdc_qformer_model* m, const void* enc, int 
         RET_IF(gemm_full(ctx, Dp, L.attn_out, t32, Dp, rows, dt, TDC_ACT_NONE, 1, h32, Dp, 1, ident, ident, ident,
                          stream));
         RET_IF(ln_map(t32, Dp, h16, h32, Dp, L.attn_ln_g, L.attn_ln_b, m->eps, rows, D, dt, ident, stream));
-        if (L.has_cross) {
+        if (L.has_cross && fused) {
+            tdc_xattn_desc x;
+            memset(&x, 0, sizeof(x));
+            x.h16 = h16; x.h32 = h32; x.ldh = Dp; x.F = F; x.K = K; x.S = S;
+            x.wq = L.cross_q_tiled; x.bq = L.cross_q.b; x.wo = L.cross_out_tiled; x.bo = L.cross_out.b;
+            x.k = kv + (size_t)L.cross_idx * D * 2; x.ldk = m->cross_k.n;
+            x.vt = ws + w.vt + (size_t)L.cross_idx * D * w.ldvt * 2; x.ldvt = (long long)w.ldvt;
+            x.bv = m->cross_bv ? m->cross_bv + (size_t)L.cross_idx * D : nullptr;
+            x.Nenc = Nenc; x.ln_g = L.cross_ln_g; x.ln_b = L.cross_ln_b; x.eps = m->eps;
+            x.dim = D; x.heads = m->heads; x.scale = scale; x.dtype = dt;
+            RET_IF(tdc_qformer_xattn(&x, stream));
+        } else if (L.has_cross) {
             RET_IF(gemm_full(h16, Dp, L.cross_q, cq, Dp, F * K, dt, TDC_ACT_NONE, 0, nullptr, 0, 0, qmap, ident, ident,
                              stream));
             tdc_attn_desc c;

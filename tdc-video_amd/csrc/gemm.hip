@@ -60,6 +60,9 @@ extern "C" int tdc_gemm(const tdc_gemm_desc* d, void* stream) {
             ((uintptr_t)d->ln_c1 & 15))
             return TDC_E_BADARG;
     }
+    if (d->c_pad8 && (d->out_f32 || d->res || d->bias || d->out_fp8 || d->act != TDC_ACT_NONE || d->c_map.seg != 0 ||
+                      d->ldc < (d->N + 7) / 8 * 8))
+        return TDC_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     if (d->out_fp8) {    /* e4m3 output: fp8 operands with their scales, whole 64-column wave tiles, 16-byte rows */
         if (!d->in_fp8 || !d->ln_stats || !d->out_stats || d->out_f32 || d->res || d->c_map.seg != 0 || d->N % 64 != 0 ||

@@ -34,9 +34,8 @@ struct GemmArgs {
     RowMap am, cm, rm;
     int tiles_m, tiles_n;
     int debug;   // tdc_gemm_set_debug(): 1 = skip the epilogue, 2 = direct (un-staged) epilogue - timing experiments only
-    int group_m;             // tile rows per group of the grouped tile order (tile_coords); TDC_GEMM_GROUP_M, default 8
-    int stagger_ticks;       // persistent kernel: start offset between the tile-column groups of an XCD, in 10-ns ticks (0 = off)
-    int stagger_xcd_ticks;   // ... and between the XCDs
+    int group_m;             // tile rows per group of the grouped tile order (tile_coords): 4 or 8, chosen per shape in launch()
+    int c_pad8;              // tdc_gemm_desc.c_pad8: rows of C are writable up to round_up(N, 8) columns
     // LayerNorm fusion (see EpiOps / slot_stats_*): producer side x16 + ln_part, consumer side ln_stats + ln_c1
     void* x16; int ldx16; float* ln_part;
     const float* ln_stats; const float* ln_c1;
@@ -930,7 +929,7 @@ __device__ __forceinline__ bool epilogue_staged_f(const GemmArgs& p, f32x4 (&acc
         epi_staged_swiglu<T, RSW, SMALL, FOLD>(p, acc, region, mbase, nbase, lane, el);
         return true;
     }
-    if (p.N & 7) return false;
+    if ((p.N & 7) && !(p.c_pad8 && !(p.N & 3))) return false;   // 16-byte stores of 8 columns: the last group may overhang N by 4
     if (p.act == TDC_ACT_GELU_ERF) epi_staged16<T, TDC_ACT_GELU_ERF, 0, R16, SMALL, FOLD>(p, acc, region, mbase, nbase, lane, el);
     else if (p.act == TDC_ACT_GELU_TANH) epi_staged16<T, TDC_ACT_GELU_TANH, 0, R16, SMALL, FOLD>(p, acc, region, mbase, nbase, lane, el);
     else if (res == 2) { if (FOLD) return false; epi_staged16<T, 0, 2, R16, SMALL, false>(p, acc, region, mbase, nbase, lane, el); }
@@ -1203,20 +1202,9 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
     const int chunk_len = cq + (xcd < cr ? 1 : 0);
     const int n_my = l < chunk_len ? (chunk_len - l + G8 - 1) / G8 : 0;
     if (n_my == 0) return;
-    // ---- start offsets (experiment switches, both off by default).  Workgroups that start together reach every tile seam
-    // together, and 256 CUs draining their C tiles at once share the chip's ~8 TB/s of fabric bandwidth (tools/store_bw.cpp:
-    // a CU alone stores a 128-KiB tile in 1.0 us, all 256 together in 3.6-4.4 us; the fp32 read-modify-write tiles move
-    // 512 KiB each and their drain runs at the HBM rate).  The tile period is the same for every CU, so a start offset would
-    // persist.  Measured (tools/bench_gemm_epi.py, TDC_GEMM_STAGGER_NS / TDC_GEMM_STAGGER_XCD_NS): offsetting the four
-    // tile-column groups of an XCD shortens the drain but costs the main loop as much (the groups stop sharing operand
-    // panels in flight in L2): no net gain at 1-8 us.  Splitting an XCD's CUs into two half-sets on disjoint halves of the
-    // XCD's chunk (each keeps its own operand sharing), the second set starting about half a tile period late: 2-3 % SLOWER
-    // on every tower shape (main loops 397 -> 412 ms per 256 frames, epilogue share unchanged) - removed again.
-    if (p.stagger_ticks > 0 || p.stagger_xcd_ticks > 0) {
-        const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)((l >> 3) & 3) * p.stagger_ticks +
-                                         (unsigned long long)xcd * p.stagger_xcd_ticks;
-        while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
-    }
+    // (Start offsets between the tile-column groups of an XCD, between XCDs, and two half-XCD sets half a tile period apart were
+    // measured in round 2 - profiles/r02_gemm_stagger*.log, DESIGN.md section 4 - and removed: the drain gets shorter and the
+    // main loop loses as much, because CUs out of lockstep stop sharing operand panels in flight in L2.)
     // ---- staging cursor: SGPR bases + per-lane byte offsets of the tile being staged
     unsigned a_so[2][2], w_so[2][2];
     const char* a_base;
@@ -1484,13 +1472,16 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
 #undef T2_MMA
 
 // workgroups of the persistent kernel = CUs of the device rounded down to a multiple of 8 (one per CU: 160 KiB of LDS);
-// 0 disables it (TDC_GEMM_PERSIST=0, or a device whose LDS cannot hold 160 KiB per workgroup)
+// 0 disables it (a device whose LDS cannot hold 160 KiB per workgroup; diagnostics builds: TDC_GEMM_PERSIST=0)
 inline int persistent_grid() {
     static int grid[kMaxDev];
     static bool known[kMaxDev];
     const int dev = current_device();
     if (!known[dev]) {
-        const char* e = getenv("TDC_GEMM_PERSIST");
+        const char* e = nullptr;
+#ifdef TDC_GEMM_DIAG
+        e = getenv("TDC_GEMM_PERSIST");
+#endif
         hipDeviceProp_t prop;
         if ((e && atoi(e) == 0) || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
             prop.sharedMemPerBlock < (size_t)T2P_LDS)
@@ -1502,8 +1493,9 @@ inline int persistent_grid() {
     return grid[dev];
 }
 
-// kernel choice: the 256^2 8-phase kernel needs enough tiles to fill the 256 CUs; TDC_GEMM_FORCE=128|256 overrides
+// kernel choice: the 256^2 8-phase kernel needs enough tiles to fill the 256 CUs (diagnostics builds: TDC_GEMM_FORCE=128|256)
 inline bool use_256(int M, int N, int K) {
+#ifdef TDC_GEMM_DIAG
     static int force = -1;
     if (force < 0) {
         const char* e = getenv("TDC_GEMM_FORCE");
@@ -1511,6 +1503,7 @@ inline bool use_256(int M, int N, int K) {
     }
     if (force == 128) return false;
     if (force == 256) return true;
+#endif
     const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256);
     return t256 >= 192 && K >= 128;
 }
@@ -1533,9 +1526,8 @@ int launch(const tdc_gemm_desc* d, hipStream_t st) {
     a.out_fp8 = d->out_fp8; a.out_stats = d->out_stats; a.out_w2max = d->out_w2max; a.out_bmax = d->out_bmax;
     a.out_wscale = d->out_wscale;
     a.debug = tdc_gemm_debug_mode;
-    a.stagger_ticks = 0;
-    a.stagger_xcd_ticks = 0;
     a.group_m = GROUP_M_DEFAULT;
+    a.c_pad8 = d->c_pad8;
 #ifdef TDC_GEMM_DIAG
     { const char* e = getenv("TDC_GEMM_DIAGMODE"); a.diag_mode = e ? atoi(e) : 0; }
 #endif
@@ -1553,10 +1545,11 @@ int launch(const tdc_gemm_desc* d, hipStream_t st) {
             // along the columns of its GROUP_M tile rows.  With >= 8 column tiles a 4 x 8 patch keeps the 4 activation panels
             // L2-resident from one round to the next (PMC, fabric bytes / algorithmic bytes: N = 8192 5.06 -> 4.22, N = 3456
             // 3.22 -> 2.51, N = 4352 2.59 -> 2.28; 0.8 % faster); the 5- and 6-column GEMMs are better off at 8 (2.39 vs 2.63).
-            // TDC_GEMM_GROUP_M overrides.  The order never changes a result.
-            static int gm_env = -2;
-            if (gm_env == -2) { const char* e = getenv("TDC_GEMM_GROUP_M"); gm_env = e ? atoi(e) : 0; }
-            a.group_m = gm_env > 0 ? gm_env : (a.tiles_n >= 8 ? 4 : 8);
+            // The order never changes a result.  (Diagnostics builds: TDC_GEMM_GROUP_M overrides.)
+            a.group_m = a.tiles_n >= 8 ? 4 : 8;
+#ifdef TDC_GEMM_DIAG
+            { const char* e = getenv("TDC_GEMM_GROUP_M"); if (e && atoi(e) > 0) a.group_m = atoi(e); }
+#endif
         }
         // hipFuncSetAttribute is per device: one flag per device and instantiation
         const int dev = current_device();
@@ -1583,14 +1576,6 @@ int launch(const tdc_gemm_desc* d, hipStream_t st) {
                 HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm256p_kernel<T, true, FP8>,
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, T2P_LDS));
                 attr256p = true;
-            }
-            {   // start-offset experiments (see the kernel): off unless the environment asks
-                static int st_env = -2, stx_env = -2;
-                if (st_env == -2) { const char* e = getenv("TDC_GEMM_STAGGER_NS"); st_env = e ? atoi(e) : 0; }
-                if (stx_env == -2) { const char* e = getenv("TDC_GEMM_STAGGER_XCD_NS"); stx_env = e ? atoi(e) : 0; }
-                const int tiles_per_cu = (a.tiles_m * a.tiles_n) / G;
-                a.stagger_ticks = tiles_per_cu >= 8 ? st_env / 10 : 0;
-                a.stagger_xcd_ticks = tiles_per_cu >= 8 ? stx_env / 10 : 0;
             }
             if (d->ln_stats) hipLaunchKernelGGL((gemm256p_kernel<T, true, FP8>), dim3(G), dim3(512), T2P_LDS, st, a);
             else hipLaunchKernelGGL((gemm256p_kernel<T, false, FP8>), dim3(G), dim3(512), T2P_LDS, st, a);

@@ -23,7 +23,7 @@ class GemmDesc(C.Structure):
                 ("x16", C.c_void_p), ("ldx16", C.c_int), ("ln_part", C.c_void_p),
                 ("ln_stats", C.c_void_p), ("ln_c1", C.c_void_p), ("in_fp8", C.c_int),
                 ("out_fp8", C.c_int), ("out_stats", C.c_void_p), ("out_w2max", C.c_float), ("out_bmax", C.c_float),
-                ("out_wscale", C.c_float)]
+                ("out_wscale", C.c_float), ("c_pad8", C.c_int)]
 
 
 class LnDesc(C.Structure):
@@ -110,14 +110,26 @@ class QformerLayer(C.Structure):
                 ("has_cross", C.c_int), ("cross_idx", C.c_int),
                 ("cross_q", Lin), ("cross_out", Lin), ("cross_ln_g", C.c_void_p), ("cross_ln_b", C.c_void_p),
                 ("fq1", Lin), ("fq2", Lin), ("fq_ln_g", C.c_void_p), ("fq_ln_b", C.c_void_p),
-                ("ft1", Lin), ("ft2", Lin), ("ft_ln_g", C.c_void_p), ("ft_ln_b", C.c_void_p)]
+                ("ft1", Lin), ("ft2", Lin), ("ft_ln_g", C.c_void_p), ("ft_ln_b", C.c_void_p),
+                ("cross_q_tiled", C.c_void_p), ("cross_out_tiled", C.c_void_p)]
 
 
 class QformerModel(C.Structure):
     _fields_ = [("dtype", C.c_int), ("dim", C.c_int), ("heads", C.c_int), ("n_layers", C.c_int), ("H", C.c_int),
                 ("eps", C.c_float), ("word", C.c_void_p), ("pos", C.c_void_p), ("ldw", C.c_int),
                 ("emb_ln_g", C.c_void_p), ("emb_ln_b", C.c_void_p), ("cross_kv", Lin), ("vision_proj", Lin),
-                ("layers_host", C.POINTER(QformerLayer))]
+                ("layers_host", C.POINTER(QformerLayer)),
+                ("cross_k", Lin), ("cross_v", Lin), ("cross_bv", C.c_void_p)]
+
+
+class XattnDesc(C.Structure):
+    _fields_ = [("h16", C.c_void_p), ("h32", C.c_void_p), ("ldh", C.c_int),
+                ("F", C.c_int), ("K", C.c_int), ("S", C.c_int),
+                ("wq", C.c_void_p), ("bq", C.c_void_p), ("wo", C.c_void_p), ("bo", C.c_void_p),
+                ("k", C.c_void_p), ("ldk", C.c_int),
+                ("vt", C.c_void_p), ("ldvt", C.c_longlong), ("bv", C.c_void_p),
+                ("Nenc", C.c_int), ("ln_g", C.c_void_p), ("ln_b", C.c_void_p), ("eps", C.c_float),
+                ("dim", C.c_int), ("heads", C.c_int), ("scale", C.c_float), ("dtype", C.c_int)]
 
 
 # name -> (restype, argtypes); every symbol include/tdc_hip.h declares
@@ -156,6 +168,9 @@ SIGNATURES = {
     "tdc_qformer_fwd": (C.c_int, [C.POINTER(QformerModel), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                   C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
                                   C.c_void_p]),
+    "tdc_qformer_xattn_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "tdc_qformer_xattn": (C.c_int, [C.POINTER(XattnDesc), C.c_void_p]),
+    "tdc_qformer_xattn_tile_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "tdc_preprocess_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "tdc_preprocess_frames": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,

@@ -11,6 +11,8 @@ from . import lib as L
 
 # bench.py sets PROFILE to a dict to time kernels with events on the launch stream: {"gemm": [(e0, e1, flops)], ...}
 PROFILE = None
+# a launch made while TAG is set is also recorded under PROFILE["tag:" + TAG] (the Q-Former cross-attention block's launches)
+TAG = None
 
 
 def _prof_begin(kind):
@@ -27,6 +29,8 @@ def _prof_end(kind, e0, work):
     e1 = torch.cuda.Event(enable_timing=True)
     e1.record()
     PROFILE[kind].append((e0, e1, work))
+    if TAG is not None and "tag:" + TAG in PROFILE:
+        PROFILE["tag:" + TAG].append((e0, e1, work, kind))
 
 
 def _dt(t):
@@ -82,7 +86,7 @@ FP8_DTYPES = (torch.uint8, torch.float8_e4m3fn)
 
 def gemm(a, w, bias=None, act=L.ACT_NONE, res=None, out=None, out_f32=False, M=None, a_map=None, c_map=None,
          r_map=None, out_rows=None, x16=None, ln_part=None, ln_stats=None, ln_c1=None, out_dtype=None, out_stats=None,
-         out_w2max=0.0, out_bmax=0.0, out_wscale=1.0):
+         out_w2max=0.0, out_bmax=0.0, out_wscale=1.0, c_pad8=False):
     """out[c_map(m)] = act(a[a_map(m)] @ w.T + bias) + res[r_map(m)].  a [Ra, lda], w [N, K] (both 16-bit).
     LayerNorm fusion (include/tdc_hip.h): x16 / ln_part = producer outputs (16-bit copy of the fp32 result, per-slot
     (mean, M2) partials [N/64, M, 2]); ln_stats [M, 2] / ln_c1 [N] = consumer inputs (a = raw rows, w = folded weight).
@@ -147,6 +151,9 @@ def gemm(a, w, bias=None, act=L.ACT_NONE, res=None, out=None, out_f32=False, M=N
     if out8:
         d.out_fp8, d.out_stats = 1, out_stats.data_ptr()
         d.out_w2max, d.out_bmax, d.out_wscale = float(out_w2max), float(out_bmax), float(out_wscale)
+    if c_pad8:      # rows of `out` writable up to round_up(N, 8) columns (tdc_gemm_desc.c_pad8)
+        assert bias is None and res is None and not out_f32 and act == L.ACT_NONE and out.shape[1] >= (N + 7) // 8 * 8
+        d.c_pad8 = 1
     e0 = _prof_begin("gemm")
     L.check(L.load().tdc_gemm(C.byref(d), _stream()), "tdc_gemm")
     if e0 is not None:
@@ -222,7 +229,9 @@ def layernorm(x, gamma, beta, eps, cols, dtype, y16=None, y32=None, add=None, ad
         assert y8_stats is not None and y8_stats.dtype == torch.float32 and y8_stats.is_contiguous()
         assert y8_stats.numel() >= 2 * (ymax + 1)
         d.y8, d.ldy8, d.y8_stats, d.y8_wscale = y8.data_ptr(), y8.stride(0), y8_stats.data_ptr(), float(y8_wscale)
+    e0 = _prof_begin("ln")
     L.check(L.load().tdc_layernorm(C.byref(d), _stream()), "tdc_layernorm")
+    _prof_end("ln", e0, 0.0)
     return y16, y32
 
 
@@ -450,6 +459,48 @@ def qformer_embed(query, qsrc, word, pos, ids, gamma, beta, eps, F, K, cols, dty
     d.F, d.K, d.cols, d.dtype = F, K, cols, _dtcode(dtype)
     L.check(L.load().tdc_qformer_embed(C.byref(d), _stream()), "tdc_qformer_embed")
     return h32, h16
+
+
+def qformer_xattn_supported(dim, heads, K, Nenc):
+    return bool(L.load().tdc_qformer_xattn_supported(dim, heads, K, Nenc))
+
+
+def xattn_tile_weight(w):
+    """[>= 768, ld] 16-bit nn.Linear weight -> its fragment-major copy for tdc_qformer_xattn (768 * 768 values, flat)."""
+    _chk2d(w, "w")
+    assert w.shape[0] >= 768 and w.shape[1] >= 768
+    out = torch.empty(768 * 768, device=w.device, dtype=w.dtype)
+    L.check(L.load().tdc_qformer_xattn_tile_weight(_ptr(w), w.stride(0), _ptr(out), _dt(w), _stream()),
+            "tdc_qformer_xattn_tile_weight")
+    return out
+
+
+def qformer_xattn(h16, h32, F, K, S, wq_t, bq, wo_t, bo, k, vt, bv, Nenc, ln_g, ln_b, eps, dim, heads, scale):
+    """The Q-Former cross-attention block of one layer in one launch (tdc_qformer_xattn; tdc/Qformer.py:128-130,185-188,
+    205-264,285-289): the K query rows of each of the F frames in h16 / h32 [F*S, ld] are replaced by
+    LayerNorm(softmax(q k^T * scale) v Wo^T + bo + h), q = h Wq^T + bq.  wq_t / wo_t: xattn_tile_weight() copies of the two
+    weights; k [F*Nenc, >= dim] (a column view of the stacked key rows), vt [dim, ldvt] (a row view of the stacked TRANSPOSED
+    values, no bias), bv [dim] fp32."""
+    for t in (h16, h32, k, vt):
+        _chk2d(t, "xattn operand")
+    assert h32.dtype == torch.float32 and h16.dtype == wq_t.dtype == wo_t.dtype == k.dtype == vt.dtype
+    assert h16.shape[0] >= F * S and h32.shape[0] >= F * S and h16.stride(0) == h32.stride(0) and h16.shape[1] >= dim
+    assert wq_t.is_cuda and wo_t.is_cuda and wq_t.is_contiguous() and wo_t.is_contiguous()
+    assert wq_t.numel() == dim * dim and wo_t.numel() == dim * dim
+    assert k.shape[0] >= F * Nenc and k.shape[1] >= dim and vt.shape[0] >= dim and vt.shape[1] >= F * Nenc
+    for v in (bq, bo, ln_g, ln_b) + ((bv,) if bv is not None else ()):
+        assert v.dtype == torch.float32 and v.is_contiguous() and v.numel() >= dim
+    d = L.XattnDesc()
+    d.h16, d.h32, d.ldh = h16.data_ptr(), h32.data_ptr(), h16.stride(0)
+    d.F, d.K, d.S = F, K, S
+    d.wq, d.bq, d.wo, d.bo = wq_t.data_ptr(), bq.data_ptr(), wo_t.data_ptr(), bo.data_ptr()
+    d.k, d.ldk = k.data_ptr(), k.stride(0)
+    d.vt, d.ldvt, d.bv = vt.data_ptr(), vt.stride(0), bv.data_ptr() if bv is not None else None
+    d.Nenc, d.ln_g, d.ln_b, d.eps = Nenc, ln_g.data_ptr(), ln_b.data_ptr(), eps
+    d.dim, d.heads, d.scale, d.dtype = dim, heads, scale, _dt(h16)
+    e0 = _prof_begin("xattn")
+    L.check(L.load().tdc_qformer_xattn(C.byref(d), _stream()), "tdc_qformer_xattn")
+    _prof_end("xattn", e0, 4.0 * F * K * dim * dim + 4.0 * F * K * Nenc * dim)
 
 
 def fbank(wav, tables, dtype, want_plain=False, mean=15.41663, std=6.55582):

@@ -49,6 +49,8 @@ class VideoEncoder:
         self.H = cfg["hidden_size"]
         self.two_streams = False
         self.native_qformer = True    # Q-Former through the C++ composite tdc_qformer_fwd
+        self.fused_xattn = True       # cross-attention block of the Q-Former as one kernel per layer (tdc_qformer_xattn) when the
+                                      # shape allows it (bert-base width, K % 16 == 0, Nenc % 4 == 0, Nenc <= 224)
         self.native_towers = True     # towers through the C++ composite tdc_vit_fwd (per-kernel Python path when False)
         self.beats = None             # beats.BeatsEncoder for raw-waveform audio input
 
@@ -405,7 +407,19 @@ class VideoEncoder:
         Lt = 0 if ids is None else ids.numel()
         S = K + Lt
         h32, h16 = ops.qformer_embed(query, qsrc, qf.word, qf.pos, ids, qf.emb_ln[0], qf.emb_ln[1], 1e-12, F, K, Dq, dt)
-        kv_all = ops.gemm(enc, qf.cross_kv.w, qf.cross_kv.b)                  # [F*Nenc, n_cross*2*Dq]
+        # the cross-attention block: fused form = key GEMM + transposed value GEMM + one kernel per cross layer
+        fused = (getattr(self, "fused_xattn", True) and qf.cross_k is not None
+                 and ops.qformer_xattn_supported(Dq, heads, K, Nenc))
+        if fused:
+            self._tile_cross_weights()
+        ops.TAG = "xattn_block"
+        if fused:
+            k_all = ops.gemm(enc, qf.cross_k.w, qf.cross_k.b, M=F * Nenc)     # [F*Nenc, n_cross*Dq]
+            vt_all = torch.empty(qf.cross_v.w.shape[0], pad64(F * Nenc), device=self.dev, dtype=dt)
+            ops.gemm(qf.cross_v.w, enc[:F * Nenc], out=vt_all, c_pad8=True)   # V^T = Wv enc^T: [n_cross*Dq, F*Nenc]
+        else:
+            kv_all = ops.gemm(enc, qf.cross_kv.w, qf.cross_kv.b)              # [F*Nenc, n_cross*2*Dq]
+        ops.TAG = None
         Dp = h16.shape[1]
         ctx = torch.zeros(F * S, Dp, device=self.dev, dtype=dt)
         ctx_q = torch.zeros(F * K, Dp, device=self.dev, dtype=dt)
@@ -420,7 +434,13 @@ class VideoEncoder:
                           S * ld, S * ld, S * ld, S * ctx.stride(0))
             ops.gemm(ctx, Lr.attn_out.w, Lr.attn_out.b, res=h32, out=t32, out_f32=True)
             ops.layernorm(t32, Lr.attn_ln[0], Lr.attn_ln[1], 1e-12, Dq, dt, y16=h16, y32=h32)
-            if Lr.cross is not None:
+            ops.TAG = "xattn_block"
+            if Lr.cross is not None and fused:
+                j = Lr.cross.idx
+                ops.qformer_xattn(h16, h32, F, K, S, Lr.cross.q_tiled, Lr.cross.q.b, Lr.cross.out_tiled, Lr.cross.out.b,
+                                  k_all[:, j * Dq:(j + 1) * Dq], vt_all[j * Dq:(j + 1) * Dq], qf.cross_bv[j * Dq:(j + 1) * Dq],
+                                  Nenc, Lr.cross.ln[0], Lr.cross.ln[1], 1e-12, Dq, heads, scale)
+            elif Lr.cross is not None:
                 cq = ops.gemm(h16, Lr.cross.q.w, Lr.cross.q.b, M=F * K, a_map=qmap)          # [F*K, Dq]
                 j = Lr.cross.idx
                 kk = kv_all[:, j * 2 * Dq: j * 2 * Dq + Dq]
@@ -431,6 +451,7 @@ class VideoEncoder:
                 ops.gemm(ctx_q, Lr.cross.out.w, Lr.cross.out.b, res=h32, r_map=qmap, out=t32, out_f32=True, M=F * K)
                 ops.layernorm(t32, Lr.cross.ln[0], Lr.cross.ln[1], 1e-12, Dq, dt, y16=h16, y32=h32, rows=F * K,
                               y_map=qmap)
+            ops.TAG = None
             m = ops.gemm(h16, Lr.ffn_q.fc1.w, Lr.ffn_q.fc1.b, act=L.ACT_GELU_ERF, M=F * K, a_map=qmap)
             ops.gemm(m, Lr.ffn_q.fc2.w, Lr.ffn_q.fc2.b, res=h32, r_map=qmap, out=t32, out_f32=True, M=F * K)
             if Lt:
@@ -541,11 +562,23 @@ class VideoEncoder:
             raise RuntimeError("query_type='learned' needs `query_tokens` in the state dict")
         return qt
 
+    def _tile_cross_weights(self):
+        """fragment-major copies of the cross-attention query / output weights for tdc_qformer_xattn (made once, on the device)"""
+        qf = self.c.qformer
+        if qf.cross_k is None:
+            return
+        for Lr in qf.layers:
+            if Lr.cross is not None and Lr.cross.q_tiled is None:
+                Lr.cross.q_tiled = ops.xattn_tile_weight(Lr.cross.q.w)
+                Lr.cross.out_tiled = ops.xattn_tile_weight(Lr.cross.out.w)
+
     def _qformer_struct(self):
         """ctypes mirror of tdc_qformer_model (cached)."""
-        if getattr(self, "_qf_struct", None) is not None:
+        fused_on = bool(getattr(self, "fused_xattn", True))
+        if getattr(self, "_qf_struct", None) is not None and self._qf_struct[2] == fused_on:
             return self._qf_struct
         c, qf = self.c, self.c.qformer
+        self._tile_cross_weights()
 
         def lin(l):
             return L.Lin(l.w.data_ptr(), l.b.data_ptr() if l.b is not None else None, l.w.shape[0], l.w.shape[1])
@@ -559,6 +592,8 @@ class VideoEncoder:
                 x.has_cross, x.cross_idx = 1, Lr.cross.idx
                 x.cross_q, x.cross_out = lin(Lr.cross.q), lin(Lr.cross.out)
                 x.cross_ln_g, x.cross_ln_b = Lr.cross.ln[0].data_ptr(), Lr.cross.ln[1].data_ptr()
+                if Lr.cross.q_tiled is not None:
+                    x.cross_q_tiled, x.cross_out_tiled = Lr.cross.q_tiled.data_ptr(), Lr.cross.out_tiled.data_ptr()
             else:
                 x.has_cross, x.cross_idx, x.cross_q, x.cross_out = 0, 0, zero, zero
             x.fq1, x.fq2 = lin(Lr.ffn_q.fc1), lin(Lr.ffn_q.fc2)
@@ -572,8 +607,10 @@ class VideoEncoder:
         m.word, m.pos, m.ldw = qf.word.data_ptr(), qf.pos.data_ptr(), qf.word.stride(0)
         m.emb_ln_g, m.emb_ln_b = qf.emb_ln[0].data_ptr(), qf.emb_ln[1].data_ptr()
         m.cross_kv, m.vision_proj = lin(qf.cross_kv), lin(c.vision_proj)
+        if qf.cross_k is not None and getattr(self, "fused_xattn", True):
+            m.cross_k, m.cross_v, m.cross_bv = lin(qf.cross_k), lin(qf.cross_v), qf.cross_bv.data_ptr()
         m.layers_host = layers
-        self._qf_struct = (m, layers)
+        self._qf_struct = (m, layers, fused_on)
         return self._qf_struct
 
     def _prompt_tensor(self, prompt_ids):

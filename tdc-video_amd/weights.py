@@ -378,7 +378,8 @@ def prep_connector(sd, cfg, dtype, dev):
                 out=make_lin(sd[lp + "crossattention.output.dense.weight"],
                              sd[lp + "crossattention.output.dense.bias"], dtype, dev),
                 ln=(vec32(sd[lp + "crossattention.output.LayerNorm.weight"], dev),
-                    vec32(sd[lp + "crossattention.output.LayerNorm.bias"], dev)))
+                    vec32(sd[lp + "crossattention.output.LayerNorm.bias"], dev)),
+                q_tiled=None, out_tiled=None)   # fragment-major copies for tdc_qformer_xattn (pipeline._tile_cross_weights)
             cross_parts.append((sd[lp + "crossattention.self.key.weight"], sd[lp + "crossattention.self.key.bias"],
                                 None))
             cross_parts.append((sd[lp + "crossattention.self.value.weight"],
@@ -392,6 +393,14 @@ def prep_connector(sd, cfg, dtype, dev):
         li += 1
     q.cross_kv = stack_lins(cross_parts, dtype, dev)  # [n_cross * 2 * dim, H]: (K_j | V_j) per cross layer j
     q.n_cross = len(cross_parts) // 2
+    # the fused cross-attention block (tdc_qformer_xattn, bert-base width only) takes the same projections stacked per kind:
+    # keys with their bias; values WITHOUT it (they are the A operand of the transposed GEMM V^T = Wv enc^T) and the value
+    # biases as one fp32 vector that is added after the PV product
+    q.cross_k = q.cross_v = q.cross_bv = None
+    if q.dim == 768 and cross_parts:
+        q.cross_k = stack_lins(cross_parts[0::2], dtype, dev)
+        q.cross_v = stack_lins([(W, None, None) for (W, _, _) in cross_parts[1::2]], dtype, dev)
+        q.cross_bv = torch.cat([b.detach().to(torch.float32).reshape(-1) for (_, b, _) in cross_parts[1::2]]).to(dev).contiguous()
     c.qformer = q
     c.query_proj = make_lin(sd["query_proj.weight"], sd["query_proj.bias"], dtype, dev)
     c.vision_proj = make_lin(sd["vision_proj.weight"], sd["vision_proj.bias"], dtype, dev)

@@ -516,3 +516,51 @@ def test_qformer_embed(ops, dtype):
     ref = F.layer_norm(rows, (D,), gamma, beta, 1e-12).reshape(-1, D)
     assert (h32[:, :D] - ref).abs().max().item() < 1e-4
     assert relerr(h16[:, :D], ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("F,K,Lt,Nenc", [(5, 144, 12, 156), (37, 16, 12, 156), (3, 144, 0, 208), (2, 32, 5, 220), (7, 48, 3, 20)])
+def test_qformer_xattn_fused_block(ops, dtype, F, K, Lt, Nenc):
+    """tdc_qformer_xattn = q-proj -> softmax(q k^T / 8) v per head -> dense + residual + LayerNorm for the K query rows of every
+    frame (tdc/Qformer.py:128-130,185-188,205-264,285-289) against torch fp32 on the same 16-bit operands; the text rows of
+    the hidden stream must stay untouched.  F * K not a multiple of the 64-row workgroup (ragged last block), K = 16 (four
+    frames per workgroup), Nenc = 208 / 220 (the wider key-tile instantiation, masked tail keys), Nenc = 20 (most key tiles empty)."""
+    D, heads, H = 768, 12, 256
+    S = K + Lt
+    g = torch.Generator().manual_seed(F * 1000 + K)
+    dev = "cuda"
+
+    def rnd(*shape, s=1.0):
+        return (torch.randn(*shape, generator=g) * s)
+    h32 = rnd(F * S, D).to(dev)
+    h16 = h32.to(dtype)
+    h32 = h16.float().clone()                       # the 16-bit copy and the fp32 master agree on entry, as in the pipeline
+    wq, wo = rnd(D, D, s=0.05).to(dtype).to(dev), rnd(D, D, s=0.05).to(dtype).to(dev)
+    bq, bo, bv = rnd(D, s=0.1).to(dev), rnd(D, s=0.1).to(dev), rnd(D, s=0.1).to(dev)
+    ln_g, ln_b = (1 + 0.1 * rnd(D)).to(dev), (0.1 * rnd(D)).to(dev)
+    enc = rnd(F * Nenc, H).to(dtype).to(dev)
+    wk, wv = rnd(D, H, s=0.08).to(dtype).to(dev), rnd(D, H, s=0.08).to(dtype).to(dev)
+    bk = rnd(D, s=0.1).to(dev)
+    # operands exactly as the pipeline makes them: keys with bias, TRANSPOSED values without (both through tdc_gemm)
+    k = ops.gemm(enc, wk, bk)
+    vt = torch.empty(D, ops.pad64(F * Nenc), device=dev, dtype=dtype)
+    ops.gemm(wv, enc, out=vt, c_pad8=True)
+    assert relerr(vt[:, :F * Nenc], (enc.float() @ wv.float().t()).t()) < tol(dtype)
+    ref16, ref32 = h16.clone(), h32.clone()
+    ops.qformer_xattn(h16, h32, F, K, S, ops.xattn_tile_weight(wq), bq, ops.xattn_tile_weight(wo), bo, k, vt, bv, Nenc, ln_g, ln_b, 1e-12, D, heads, 0.125)
+    # ---- torch fp32 reference on the same operands
+    rows = (torch.arange(F, device=dev)[:, None] * S + torch.arange(K, device=dev)[None, :]).reshape(-1)
+    x = ref16[rows].float()
+    q = (x @ wq.float().t() + bq).to(dtype).float().view(F, K, heads, 64).transpose(1, 2)
+    kk = k.float().view(F, Nenc, heads, 64).transpose(1, 2)
+    vv = vt[:, :F * Nenc].float().t().reshape(F, Nenc, heads, 64).transpose(1, 2)
+    p = torch.softmax(q @ kk.transpose(-1, -2) * 0.125, dim=-1)
+    ctx = ((p @ vv).transpose(1, 2).reshape(F * K, D) + bv).to(dtype).float()
+    y = torch.nn.functional.layer_norm(ctx @ wo.float().t() + bo + ref32[rows], (D,), ln_g, ln_b, 1e-12)
+    err = (h32[rows] - y).abs().max().item()
+    assert err < (6e-3 if dtype == torch.float16 else 4e-2), err
+    assert torch.equal(h16[rows], h32[rows].to(dtype))
+    other = torch.ones(F * S, dtype=torch.bool, device=dev)
+    other[rows] = False
+    assert torch.equal(h16[other], ref16[other]) and torch.equal(h32[other], ref32[other])
+    assert not ops.qformer_xattn_supported(64, 4, 4, 16) and ops.qformer_xattn_supported(768, 12, 144, 156)
