@@ -193,6 +193,8 @@ def main():
     ap.add_argument("--gemm-shape-times", default="", help="write per-shape GEMM times of the profiled step to this file")
     ap.add_argument("--no-fused-xattn", action="store_true", help="Q-Former cross-attention block as the per-kernel sequence "
                     "(stacked K/V GEMM, q GEMM, tdc_attention, dense GEMM, LayerNorm) instead of tdc_qformer_xattn")
+    ap.add_argument("--recompute-halo", action="store_true", help="N > 1: every rank re-encodes its right neighbour's first frame "
+                    "through DINOv2 instead of receiving its features point to point (fallback form of the boundary exchange)")
     ap.add_argument("--audio", action="store_true", help="BASELINE config 4: + T seconds of 16 kHz audio through BEATs "
                     "on the device, 50 audio tokens per frame in the Q-Former KV (1 GPU only)")
     ap.add_argument("--dump-gemm-shapes", default=None, help="write the GEMM launches of one step (for tools/gemm_pmc)")
@@ -264,12 +266,14 @@ def main():
     else:
         from tdc_video_amd import dist as tdist
         vs = synth_video(lo, hi, px_s, dev, tower_dtype)       # a rank only ever holds its own frames
-        vd = synth_video(lo, hi, px_d, dev, tower_dtype, seed=4321 if px_d != px_s else 1234)
+        halo = 1 if (args.recompute_halo and lo < hi < T) else 0        # + the right neighbour's first frame, re-encoded here
+        vd = synth_video(lo, hi + halo, px_d, dev, tower_dtype, seed=4321 if px_d != px_s else 1234)
         sharded = tdist.ShardedVideoEncoder(enc, rank, world)
 
         def step():
             return sharded.encode_video(vs, vd, T, (384, 384), n_text_tokens=64, prompt_ids=prompt_ids,
-                                        audio={"audio_wav": wav} if wav is not None else None)
+                                        audio={"audio_wav": wav} if wav is not None else None,
+                                        recompute_halo=bool(args.recompute_halo))
 
     def barrier():
         if world > 1:
@@ -284,10 +288,14 @@ def main():
         out = step()
     barrier()
     dt = time.perf_counter() - t0
+    rank_ms = None
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
+        # per-rank step times (a straggler shows as max >> min), then the MAX over the ranks as the job's time
+        mine = torch.tensor([dt], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(every, mine)
+        rank_ms = [round(float(x.item()) / args.steps * 1e3, 2) for x in every]
+        dt = max(float(x.item()) for x in every)
     ms_per_step = dt / args.steps * 1e3
     fps = T * args.steps / dt
 
@@ -395,6 +403,7 @@ def main():
                                   "the Q-Former KV)" % T if args.audio else ""),
                    "frames": T, "K": K, "hidden": H, "px": px_s, "parallelism": "frames sharded over %d GPU(s)" % world,
                    "emitted_tokens": int(out.shape[0])},
+        "rank_ms_per_step": None if rank_ms is None else {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
         "roofline": roofline,
     }
     if sd_cpu is not None:

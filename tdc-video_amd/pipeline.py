@@ -235,6 +235,28 @@ class VideoEncoder:
         n = dino_feat.shape[0] // T * dino_feat.shape[1]
         return ops.frame_cossim(dino_feat, T, n)
 
+    # The segmentation is host logic on T - 1 similarities.  Reading them with .tolist() on the compute stream would also wait
+    # for whatever was enqueued behind them (the SigLIP tower: a quarter of the step) and leave the device idle while the host
+    # plans and enqueues the connector.  mark() / after(): an event behind the similarity kernel and a side stream that waits
+    # for just that event - the host gets the numbers while the tower behind them is still running.
+    def mark(self):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        return ev
+
+    def after(self, ev):
+        side = self.__dict__.get("_side_stream")
+        if side is None:
+            side = self._side_stream = torch.cuda.Stream(device=self.dev)
+        side.wait_event(ev)
+        return torch.cuda.stream(side)
+
+    def fetch(self, t, ev):
+        """device tensor t (ready at event ev) -> python list, without waiting for later work on the compute stream"""
+        with self.after(ev):
+            t.record_stream(torch.cuda.current_stream(self.dev))
+            return t.cpu().tolist()
+
     def frame_sims(self, dino_feat, T):
         """same as a python list (one D2H copy: the segmentation is host logic)."""
         return self.sims_tensor(dino_feat, T).tolist()
@@ -672,7 +694,15 @@ class VideoEncoder:
     def query_width(self):
         return pad64(self.c.qformer.dim)
 
-    def emit(self, Xf, comp, pairs, splice=None):
+    def emit_into(self, Xf, comp, pairs, out):
+        """emit() into the first len(pairs) rows of a caller-owned [>= len(pairs), H] buffer (the sharded path's send buffer)."""
+        return self.emit(Xf, comp, pairs, out=out)
+
+    def compact_rows(self, src, idx, cols):
+        """rows src[idx[:, 1]] -> a new [len(idx), cols] tensor (one tdc_gather_rows; idx validated by its builder)."""
+        return ops.gather_rows([src], idx, idx.shape[0], cols, validated=True)
+
+    def emit(self, Xf, comp, pairs, splice=None, out=None):
         """a19: one gather over (frame tokens | context tokens | frame_seg) -> [len(pairs), H].
         a21 hand-off (cambrian_arch.py:1712-1790 / cambrian_qwen.py:457-462): with
         splice = {"table": embed_tokens.weight [V, H] 16-bit on this device, "before": ids, "after": ids} the same
@@ -696,7 +726,7 @@ class VideoEncoder:
             tables.append(tab)
         ops.check_pairs_host(p_np, [t.shape[0] if t.dim() == 2 else 1 for t in tables])
         idx = torch.from_numpy(p_np).to(self.dev)
-        return ops.gather_rows(tables, idx, idx.shape[0], self.c.H, validated=True)
+        return ops.gather_rows(tables, idx, idx.shape[0], self.c.H, out=out, validated=True)
 
     def compress(self, X, T, N, seg_indices, prompt_ids, max_visual_len, audio=None, keep=None, splice=None):
         """X [T*N, Hp] -> emitted visual tokens [n, H] (tdc/cambrian_arch.py:1520-1709)."""
@@ -786,11 +816,13 @@ def encode_video_with(e, px_siglip, px_dino, image_size, budget_text_len, n_text
             px_siglip = px_siglip[s2]
             T = len(sel2)
         sims_dev = e.sims_tensor(dino, T)
+        ev = e.mark() if hasattr(e, "mark") and sims_dev.is_cuda else None
         if side is None:
             # the SigLIP tower does not depend on the selection: enqueue it BEFORE the one host read of the similarities,
-            # so the device keeps working while the host ranks them (a3)
+            # so the device keeps working while the host ranks them (a3) - and read them on a side stream (fetch), so the
+            # host does not wait for the tower either
             sig = e.tower("siglip", px_siglip)
-        seg_idx = seg.select_segments(sims_dev.tolist(), mns)
+        seg_idx = seg.select_segments(e.fetch(sims_dev, ev) if ev is not None else sims_dev.tolist(), mns)
     if side is not None:
         torch.cuda.current_stream().wait_stream(side)
         sig = sig_early

@@ -21,11 +21,11 @@ PROMPT = [101] + list(range(2000, 2010)) + [102]
 H, K, PER_RANK = 3584, 144, 16
 
 
-def _engine(T, audio=False):
+def _engine(T, audio=False, dev_index=0):
     import bench
     import tdc_video_amd  # noqa: F401
     from tdc_video_amd.pipeline import VideoEncoder
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", dev_index)
     gen = torch.Generator(device=dev).manual_seed(0)
     sd = bench.random_state_dict(H, K, dev, gen)
     enc = VideoEncoder(sd, bench.model_cfg(H, K, T), dtype=torch.bfloat16, device=dev, tower_batch=16)
@@ -47,7 +47,8 @@ def _engine(T, audio=False):
 
 def _video(lo, hi, px, seed):
     import bench
-    return bench.synth_video(lo, hi, px, torch.device("cuda", 0), torch.bfloat16, seed=seed, scene_len=5)
+    return bench.synth_video(lo, hi, px, torch.device("cuda", torch.cuda.current_device()), torch.bfloat16, seed=seed,
+                             scene_len=5)
 
 
 def _sharded(enc, wav, T, rank, world, comm=None):
@@ -67,15 +68,21 @@ def _serial(enc, wav, T):
                             audio={"audio_wav": wav} if wav is not None else None)
 
 
-def _worker(rank, world, port, audio, q):
+def _worker(rank, world, port, audio, q, backend="gloo"):
+    """backend "gloo": every rank on cuda:0 (a one-GPU box); "nccl": rank r on cuda:r - RCCL over xGMI, the product transport"""
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev_index = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev_index)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        torch.cuda.set_device(0)
         T = PER_RANK * world
-        enc, wav = _engine(T, audio)
+        enc, wav = _engine(T, audio, dev_index)
         out = _sharded(enc, wav, T, rank, world)
         ok, shape = None, tuple(out.shape)
         if rank == 0:
@@ -95,12 +102,25 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,audio", [(2, False), (2, True), (4, False)])
-def test_fullsize_sharded_processes_equal_serial(world, audio):
+def _n_gpus():
+    try:
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.parametrize("world,audio,backend", [(2, False, "gloo"), (2, True, "gloo"), (4, False, "gloo"),
+                                                 (2, False, "nccl"), (2, True, "nccl"), (4, False, "nccl"), (8, False, "nccl")])
+def test_fullsize_sharded_processes_equal_serial(world, audio, backend):
+    """backend nccl: one GPU per rank over RCCL - runs wherever the box has >= world GPUs (skipped on a one-GPU box, picked up
+    automatically on an 8-GPU node): the boundary-feature point-to-point exchange, the similarity all-gather, the query
+    hand-off and the buffered token all_gather_into_tensor on the transport the product uses."""
+    if backend == "nccl" and _n_gpus() < world:
+        pytest.skip("needs %d GPUs (RCCL: one GPU per rank)" % world)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, audio, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, audio, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in range(world)]

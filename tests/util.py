@@ -105,6 +105,12 @@ class ThreadComm:
         h.bar.wait()
         return out
 
+    def all_gather_into(self, out, t):
+        parts = self.all_gather(t)
+        n = t.shape[0]
+        for r, part in enumerate(parts):
+            out[r * n:(r + 1) * n].copy_(part)
+
     def exchange(self, sends, recvs):
         h = self.hub
         with h.lock:
