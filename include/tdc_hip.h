@@ -132,7 +132,12 @@ typedef struct {
      * softmax (score -inf BEFORE the bias is added, backbone.py:633-643) when key_mask[b*key_mask_bs + k] != 0.
      * key_mask_bs % 4 == 0, 4-byte aligned.  BEATs padded batches (BEATs.py:142-153: padding_mask of extract_features). */
     const unsigned char* key_mask; long long key_mask_bs;
+    /* kernel form: TDC_ATTN_FORM_AUTO (0) picks by shape (the 32x32x16 kernel for long sequences at head dim 64 / 72, the
+     * 16x16x32 kernels otherwise); TDC_ATTN_FORM_16X16 keeps the 16x16x32 kernels for every shape (tests compare the forms) */
+    int form;
 } tdc_attn_desc;
+#define TDC_ATTN_FORM_AUTO 0
+#define TDC_ATTN_FORM_16X16 1
 int tdc_attention(const tdc_attn_desc* d, void* stream);
 
 /* ---- small data-movement / reduction kernels ------------------------------------------------------------- */
@@ -274,6 +279,10 @@ typedef struct {
      * WITHOUT bias (it is the A operand of the transposed GEMM V^T = Wv enc^T) and cross_bv [n_cross*dim] fp32 = the value
      * biases, added after the PV product */
     tdc_lin cross_k, cross_v; const float* cross_bv;
+    /* how tdc_qformer_fwd runs the cross-attention block when the shape is one tdc_qformer_xattn supports (else 0):
+     * 0 = per-kernel sequence; 1 = q GEMM + tdc_attention, then output projection + residual + LayerNorm in one kernel
+     * (needs cross_out_tiled); 2 = the whole block in one kernel per layer (needs cross_k / cross_v / both tiled weights) */
+    int xattn_mode;
 } tdc_qformer_model;
 size_t tdc_qformer_workspace_bytes(const tdc_qformer_model* m, int F, int K, int Lt, int Nenc);
 
@@ -298,6 +307,10 @@ typedef struct {
     int Nenc;
     const float *ln_g, *ln_b; float eps;
     int dim, heads; float scale; int dtype;
+    /* ctx != NULL: the OUTPUT-PROJECTION-ONLY form - ctx [F*K, ldctx] 16-bit is the attention output of the flat query rows
+     * (row f*K + k), produced by separate launches (q GEMM, tdc_attention); the kernel then computes
+     * h[:, :K] = LayerNorm(ctx Wo^T + bo + h[:, :K]) alone: wq / bq / k / vt / bv / Nenc / scale are not read. */
+    const void* ctx; int ldctx;
 } tdc_xattn_desc;
 int tdc_qformer_xattn_supported(int dim, int heads, int K, int Nenc);
 int tdc_qformer_xattn(const tdc_xattn_desc* d, void* stream);

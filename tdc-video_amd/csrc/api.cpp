@@ -125,13 +125,23 @@ struct QfWs {
     size_t h32, h16, kv, vt, ldvt, qkv, ctx, ctxq, cq, t32, t32b, mq, mt, total;
 };
 
-// the fused cross-attention block (tdc_qformer_xattn) runs when its weights are given and the shape is one it supports
-bool qf_fused(const tdc_qformer_model* m, int K, int Nenc) {
+// form of the cross-attention block (tdc_qformer_model.xattn_mode, 0 when the weights or the shape do not allow the request):
+// 2 = the whole block in one kernel per layer, 1 = its output projection + residual + LayerNorm in one kernel, 0 = per-kernel
+int qf_mode(const tdc_qformer_model* m, int K, int Nenc) {
+    if (m->xattn_mode <= 0) return 0;
+    bool q_t = true, o_t = true;
     for (int l = 0; l < m->n_layers; ++l)
-        if (m->layers_host[l].has_cross && (!m->layers_host[l].cross_q_tiled || !m->layers_host[l].cross_out_tiled)) return false;
-    return m->cross_k.w && m->cross_v.w && m->cross_k.n == m->cross_v.n && m->cross_k.k == m->cross_v.k &&
-           tdc_qformer_xattn_supported(m->dim, m->heads, K, Nenc);
+        if (m->layers_host[l].has_cross) {
+            q_t = q_t && m->layers_host[l].cross_q_tiled;
+            o_t = o_t && m->layers_host[l].cross_out_tiled;
+        }
+    if (m->xattn_mode >= 2 && q_t && o_t && m->cross_k.w && m->cross_v.w && m->cross_k.n == m->cross_v.n &&
+        m->cross_k.k == m->cross_v.k && tdc_qformer_xattn_supported(m->dim, m->heads, K, Nenc))
+        return 2;
+    if (o_t && tdc_qformer_xattn_supported(m->dim, m->heads, K, 8)) return 1;
+    return 0;
 }
+bool qf_fused(const tdc_qformer_model* m, int K, int Nenc) { return qf_mode(m, K, Nenc) == 2; }
 
 QfWs qf_layout(const tdc_qformer_model* m, int F, int K, int Lt, int Nenc) {
     const size_t S = (size_t)K + Lt, rows = (size_t)F * S, Dp = pad64i(m->dim);
@@ -223,7 +233,8 @@ extern "C" int tdc_qformer_fwd(const tdc_qformer_model* m, const void* enc, int 
         e.F = F; e.K = K; e.cols = D; e.dtype = dt;
         RET_IF(tdc_qformer_embed(&e, stream));
     }
-    const bool fused = qf_fused(m, K, Nenc);
+    const int mode = qf_mode(m, K, Nenc);
+    const bool fused = mode == 2;
     if (fused) {
         // keys of all cross layers: one GEMM; values of all cross layers TRANSPOSED: one GEMM with the operands swapped
         // (A = Wv [n_cross*dim, H], "weight" = enc [F*Nenc, H]) - vt[c][f*Nenc + key], the A operand of the PV product
@@ -275,9 +286,18 @@ extern "C" int tdc_qformer_fwd(const tdc_qformer_model* m, const void* enc, int 
             c.q_rs = Dp; c.k_rs = c.v_rs = m->cross_kv.n; c.o_rs = Dp;
             c.batch = F; c.heads = m->heads; c.head_dim = hd; c.sq = K; c.sk = Nenc; c.scale = scale; c.dtype = dt;
             RET_IF(tdc_attention(&c, stream));
-            RET_IF(gemm_full(ctxq, Dp, L.cross_out, t32, Dp, F * K, dt, TDC_ACT_NONE, 1, h32, Dp, 1, ident, ident, qmap,
-                             stream));
-            RET_IF(ln_map(t32, Dp, h16, h32, Dp, L.cross_ln_g, L.cross_ln_b, m->eps, F * K, D, dt, qmap, stream));
+            if (mode == 1) {     // output projection + residual + LayerNorm of the K query rows in one kernel
+                tdc_xattn_desc x;
+                memset(&x, 0, sizeof(x));
+                x.h16 = h16; x.h32 = h32; x.ldh = Dp; x.F = F; x.K = K; x.S = S;
+                x.wo = L.cross_out_tiled; x.bo = L.cross_out.b; x.ln_g = L.cross_ln_g; x.ln_b = L.cross_ln_b; x.eps = m->eps;
+                x.dim = D; x.heads = m->heads; x.Nenc = Nenc; x.dtype = dt; x.ctx = ctxq; x.ldctx = Dp;
+                RET_IF(tdc_qformer_xattn(&x, stream));
+            } else {
+                RET_IF(gemm_full(ctxq, Dp, L.cross_out, t32, Dp, F * K, dt, TDC_ACT_NONE, 1, h32, Dp, 1, ident, ident, qmap,
+                                 stream));
+                RET_IF(ln_map(t32, Dp, h16, h32, Dp, L.cross_ln_g, L.cross_ln_b, m->eps, F * K, D, dt, qmap, stream));
+            }
         }
         RET_IF(gemm_full(h16, Dp, L.fq1, mq, L.fq2.k, F * K, dt, TDC_ACT_GELU_ERF, 0, nullptr, 0, 0, qmap, ident, ident,
                          stream));

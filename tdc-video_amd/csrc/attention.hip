@@ -17,7 +17,6 @@
 #include "../../include/tdc_hip.h"
 #include "attention_args.h"
 #include <stdio.h>
-#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -237,11 +236,14 @@ __global__ __launch_bounds__(256, (QT <= 2 ? 2 : 1)) void attn_kernel(AttnArgs p
             }
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            float m_new = fmaxf(m_run[t], BIAS ? mx : mx * p.scale_log2);
-            if (BIAS && m_new == -INFINITY) m_new = 0.f;          // every key so far masked: p = 0, no NaN from inf - inf
-            const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
+            const float m_new = fmaxf(m_run[t], BIAS ? mx : mx * p.scale_log2);
+            // every key so far masked: 0 is the exponent offset of THIS tile only (p = 0, no NaN from inf - inf); the running
+            // maximum stays -inf, so the first tile with a finite score re-bases (alpha = 2^(-inf) = 0 on l = 0, O = 0) instead
+            // of measuring its scores against a stale 0 - where valid scores below ~ -126 would all underflow
+            const float m_use = (BIAS && m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_use);
             m_run[t] = m_new;
-            const f32x4 nm4 = {-m_new, -m_new, -m_new, -m_new};
+            const f32x4 nm4 = {-m_use, -m_use, -m_use, -m_use};
             f32x4 rs4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
@@ -317,10 +319,7 @@ int launch_qt(const AttnArgs& a, int batch, hipStream_t st) {
     // rows): DINOv2 tower shape 603 -> 651 TFLOP/s at a 512-frame batch in isolation (2.78 -> 2.57 ms per launch; inside
     // the pipeline, behind the qkv GEMM, 2.76 -> 2.71 ms); head dim 72 needs 298 VGPRs (one wave per SIMD), loses 5 % and
     // stays at 32 rows per wave.
-    // TDC_ATTN_QT4=0 switches it off.
-    static int qt4 = -1;
-    if (qt4 < 0) { const char* e = getenv("TDC_ATTN_QT4"); qt4 = e ? atoi(e) : 1; }
-    if (qt4 && DK == 64 && !BIAS && a.sq > 256) {
+    if (DK == 64 && !BIAS && a.sq > 256) {
         dim3 grid((a.sq + 255) / 256, a.heads, batch);
         hipLaunchKernelGGL((attn_kernel<T, DK, NDV, 4, VEC, BIAS>), grid, dim3(256), 0, st, a);
     } else if (a.sq > 64) {
@@ -391,12 +390,9 @@ extern "C" int tdc_attention(const tdc_attn_desc* d, void* stream) {
     }
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype != TDC_F16 && d->dtype != TDC_BF16) return TDC_E_BADARG;
-    {   // long sequences at head dim 64 / 72 (the towers): the 32x32x16 form; TDC_ATTN32=0 keeps the 16x16x32 kernels
-        const char* e = getenv("TDC_ATTN32");      // read per call: tests and tools/bench_attn.py switch forms in one process
-        if (!e || atoi(e) != 0) {
-            const int rc = tdc_attention32(a, d->batch, d->dtype, st);
-            if (rc != -1) return rc;
-        }
+    if (d->form != TDC_ATTN_FORM_16X16) {   // long sequences at head dim 64 / 72 (the towers): the 32x32x16 form
+        const int rc = tdc_attention32(a, d->batch, d->dtype, st);
+        if (rc != -1) return rc;
     }
     if (d->dtype == TDC_F16) return launch<f16>(a, d->batch, st);
     if (d->dtype == TDC_BF16) return launch<bf16>(a, d->batch, st);

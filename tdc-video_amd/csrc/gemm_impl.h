@@ -1515,7 +1515,7 @@ unsigned long long* tdc_gemm_diag_wstamps = nullptr;
 namespace {
 #endif
 template <class T, bool FP8>
-int launch(const tdc_gemm_desc* d, hipStream_t st) {
+int launch(const tdc_gemm_desc* d, hipStream_t st, bool force128 = false) {
     GemmArgs a;
     a.A = d->A; a.W = d->W; a.C = d->C; a.bias = d->bias; a.res = d->res;
     a.lda = d->lda; a.ldw = d->ldw; a.ldc = d->ldc; a.ldres = d->ldres;
@@ -1538,7 +1538,7 @@ int launch(const tdc_gemm_desc* d, hipStream_t st) {
     a.am = RowMap::make(d->a_map.seg, d->a_map.stride, d->a_map.off, d->a_map.inner);
     a.cm = RowMap::make(d->c_map.seg, d->c_map.stride, d->c_map.off, d->c_map.inner);
     a.rm = RowMap::make(d->r_map.seg, d->r_map.stride, d->r_map.off, d->r_map.inner);
-    if (use_256(a.M, a.N, a.K)) {
+    if (!force128 && use_256(a.M, a.N, a.K)) {
         a.tiles_m = (a.M + 255) / 256;
         a.tiles_n = (a.N + 255) / 256;
         {   // group height of the tile order: the 32 concurrent tiles of an XCD form a GROUP_M x (32 / GROUP_M) patch that walks

@@ -48,6 +48,7 @@ constexpr int XBUF = XROWS * XD * 2;
 
 struct XattnArgs {
     const void* h16; float* h32; void* h16_out; int ldh;
+    const void* ctx; int ldctx;           // OUT_ONLY form: the attention output of the flat query rows [rows, ldctx]
     int rows, K, S;                       // rows = F*K flat query rows; global row of flat row r: (r / K) * S + r % K
     unsigned invK;                        // floor(2^32 / K)
     const void *wq, *wo; const float *bq, *bo;     // wq / wo: fragment-major copies (tdc_qformer_xattn_tile_weight)
@@ -152,7 +153,9 @@ __device__ __forceinline__ void gemm_64x768(const T* __restrict__ Wt, const char
     }
 }
 
-template <class T, int NKT>     // NKT: key tiles of 16 (even), Nenc <= 16 NKT
+// NKT: key tiles of 16 (even), Nenc <= 16 NKT.  OUT_ONLY: the block's last third alone - ctx (the attention output, read from
+// global memory) -> output projection + residual + LayerNorm; q projection and attention stay separate launches in front of it.
+template <class T, int NKT, bool OUT_ONLY>
 __global__ __launch_bounds__(512, 2) void xattn_kernel(XattnArgs p) {
     typedef typename VecOf<T>::v8 v8;
     typedef typename VecOf<T>::v4 v4;
@@ -172,22 +175,24 @@ __global__ __launch_bounds__(512, 2) void xattn_kernel(XattnArgs p) {
     }
     const int r0 = bid * XROWS;
 
-    // ---- stage the hidden rows (16-bit copy) of the block: 64 x 96 chunks of 16 bytes
+    // ---- stage the hidden rows (16-bit copy) of the block - or, OUT_ONLY, its attention output rows: 64 x 96 chunks of 16 bytes
     {
-        const T* H = (const T*)p.h16;
+        const T* H = (const T*)(OUT_ONLY ? p.ctx : p.h16);
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
             const int idx = tid + j * 512;
             const int row = idx / 96, ch = idx - row * 96;
             int flat = r0 + row;
             if (flat > p.rows - 1) flat = p.rows - 1;
-            const v8 v = *(const v8*)(H + (long long)grow_of(flat, p.K, p.S, p.invK) * p.ldh + ch * 8);
+            const long long src = OUT_ONLY ? (long long)flat * p.ldctx : (long long)grow_of(flat, p.K, p.S, p.invK) * p.ldh;
+            const v8 v = *(const v8*)(H + src + ch * 8);
             *(v8*)(buf + buf_off(row, ch * 8)) = v;
         }
     }
     __syncthreads();
 
     f32x4 acc[6][4];
+    if constexpr (!OUT_ONLY) {
     // ---- P1: q = h Wq^T + bq
 #pragma unroll
     for (int nt = 0; nt < 6; ++nt)
@@ -377,6 +382,7 @@ __global__ __launch_bounds__(512, 2) void xattn_kernel(XattnArgs p) {
         }
     }
     __syncthreads();
+    }   // !OUT_ONLY
 
     // ---- P3: out = ctx Wo^T + bo + residual, LayerNorm
 #pragma unroll
@@ -481,20 +487,21 @@ template <class T>
 int launch(const XattnArgs& a, int nkt, hipStream_t st) {
 
     const int grid = ((a.nblocks + 7) / 8) * 8;
-#define XLAUNCH(N)                                                                                                       \
+#define XLAUNCH(N, OO)                                                                                                    \
     do {                                                                                                                 \
-        const size_t lds = XBUF + 2 * 8 * 64 * sizeof(float) + 2 * N * 2048;  /* rows, LayerNorm partials, K / V^T ring */ \
+        const size_t lds = XBUF + 2 * 8 * 64 * sizeof(float) + (OO ? 0 : 2 * N * 2048);  /* rows, LayerNorm partials, K / V^T ring */ \
         static bool attr[16];                                                                                            \
         int dev = 0;                                                                                                     \
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return TDC_E_BADARG;                               \
         if (!attr[dev]) {                                                                                                \
-            HIP_CHECK_RET(hipFuncSetAttribute((const void*)xattn_kernel<T, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)xattn_kernel<T, N, OO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             attr[dev] = true;                                                                                            \
         }                                                                                                                \
-        hipLaunchKernelGGL((xattn_kernel<T, N>), dim3(grid), dim3(512), lds, st, a);                                     \
+        hipLaunchKernelGGL((xattn_kernel<T, N, OO>), dim3(grid), dim3(512), lds, st, a);                                 \
     } while (0)
-    if (nkt <= 10) XLAUNCH(10);
-    else XLAUNCH(14);
+    if (a.ctx) XLAUNCH(10, true);
+    else if (nkt <= 10) XLAUNCH(10, false);
+    else XLAUNCH(14, false);
 #undef XLAUNCH
     return (int)hipGetLastError();
 }
@@ -526,21 +533,27 @@ extern "C" int tdc_qformer_xattn_tile_weight(const void* w, int ldw, void* out, 
 }
 
 extern "C" int tdc_qformer_xattn(const tdc_xattn_desc* d, void* stream) {
-    if (!d || !d->h16 || !d->h32 || !d->wq || !d->wo || !d->bq || !d->bo || !d->k || !d->vt || !d->ln_g || !d->ln_b)
-        return TDC_E_BADARG;
-    if (!tdc_qformer_xattn_supported(d->dim, d->heads, d->K, d->Nenc) || d->F <= 0 || d->S < d->K) {
+    if (!d || !d->h16 || !d->h32 || !d->wo || !d->bo || !d->ln_g || !d->ln_b) return TDC_E_BADARG;
+    const bool out_only = d->ctx != nullptr;
+    if (!out_only && (!d->wq || !d->bq || !d->k || !d->vt)) return TDC_E_BADARG;
+    if (!tdc_qformer_xattn_supported(d->dim, d->heads, d->K, out_only ? 8 : d->Nenc) || d->F <= 0 || d->S < d->K) {
         fprintf(stderr, "[tdc_hip] tdc_qformer_xattn: unsupported shape (dim=%d heads=%d K=%d Nenc=%d)\n", d->dim, d->heads, d->K,
                 d->Nenc);
         return TDC_E_BADARG;
     }
     auto al = [](const void* p, int bytes) { return ((uintptr_t)p % bytes) == 0; };
-    if (d->ldh % 8 || d->ldh < XD || d->ldk % 8 || d->ldk < XD || d->ldvt % 4 ||
-        d->ldvt < (long long)d->F * d->Nenc || !al(d->h16, 16) || !al(d->h32, 16) || !al(d->wq, 16) || !al(d->wo, 16) ||
-        !al(d->k, 16) || !al(d->vt, 8) || !al(d->bq, 16) || !al(d->bo, 16) || !al(d->ln_g, 16) || !al(d->ln_b, 16) ||
-        (d->bv && !al(d->bv, 16)) || (long long)d->F * d->K > 0x7fffffffll || (long long)d->F * d->S * d->ldh > 0x7fffffffll)
+    if (d->ldh % 8 || d->ldh < XD || !al(d->h16, 16) || !al(d->h32, 16) || !al(d->wo, 16) || !al(d->bo, 16) || !al(d->ln_g, 16) ||
+        !al(d->ln_b, 16) || (long long)d->F * d->K > 0x7fffffffll || (long long)d->F * d->S * d->ldh > 0x7fffffffll)
         return TDC_E_BADARG;
+    if (out_only) {
+        if (d->ldctx % 8 || d->ldctx < XD || !al(d->ctx, 16)) return TDC_E_BADARG;
+    } else if (d->ldk % 8 || d->ldk < XD || d->ldvt % 4 || d->ldvt < (long long)d->F * d->Nenc || !al(d->wq, 16) || !al(d->k, 16) ||
+               !al(d->vt, 8) || !al(d->bq, 16) || (d->bv && !al(d->bv, 16))) {
+        return TDC_E_BADARG;
+    }
     XattnArgs a;
     a.h16 = d->h16; a.h32 = d->h32; a.h16_out = d->h16; a.ldh = d->ldh;
+    a.ctx = d->ctx; a.ldctx = d->ldctx;
     a.rows = d->F * d->K; a.K = d->K; a.S = d->S;
     a.invK = (unsigned)((1ull << 32) / (unsigned long long)d->K);
     a.wq = d->wq; a.wo = d->wo; a.bq = d->bq; a.bo = d->bo;

@@ -44,7 +44,7 @@ class AttnDesc(C.Structure):
                 ("scale", C.c_float), ("dtype", C.c_int),
                 ("bias", C.c_void_p), ("bias_hs", C.c_longlong), ("bias_rs", C.c_int),
                 ("gate", C.c_void_p), ("gate_rs", C.c_int),
-                ("key_mask", C.c_void_p), ("key_mask_bs", C.c_longlong)]
+                ("key_mask", C.c_void_p), ("key_mask_bs", C.c_longlong), ("form", C.c_int)]
 
 
 class GatherTables(C.Structure):
@@ -119,7 +119,7 @@ class QformerModel(C.Structure):
                 ("eps", C.c_float), ("word", C.c_void_p), ("pos", C.c_void_p), ("ldw", C.c_int),
                 ("emb_ln_g", C.c_void_p), ("emb_ln_b", C.c_void_p), ("cross_kv", Lin), ("vision_proj", Lin),
                 ("layers_host", C.POINTER(QformerLayer)),
-                ("cross_k", Lin), ("cross_v", Lin), ("cross_bv", C.c_void_p)]
+                ("cross_k", Lin), ("cross_v", Lin), ("cross_bv", C.c_void_p), ("xattn_mode", C.c_int)]
 
 
 class XattnDesc(C.Structure):
@@ -129,7 +129,8 @@ class XattnDesc(C.Structure):
                 ("k", C.c_void_p), ("ldk", C.c_int),
                 ("vt", C.c_void_p), ("ldvt", C.c_longlong), ("bv", C.c_void_p),
                 ("Nenc", C.c_int), ("ln_g", C.c_void_p), ("ln_b", C.c_void_p), ("eps", C.c_float),
-                ("dim", C.c_int), ("heads", C.c_int), ("scale", C.c_float), ("dtype", C.c_int)]
+                ("dim", C.c_int), ("heads", C.c_int), ("scale", C.c_float), ("dtype", C.c_int),
+                ("ctx", C.c_void_p), ("ldctx", C.c_int)]
 
 
 # name -> (restype, argtypes); every symbol include/tdc_hip.h declares

@@ -236,7 +236,7 @@ def layernorm(x, gamma, beta, eps, cols, dtype, y16=None, y32=None, add=None, ad
 
 
 def attention(q, k, v, out, batch, heads, head_dim, sq, sk, scale, q_bs, k_bs, v_bs, o_bs, bias=None, gate=None,
-              key_mask=None):
+              key_mask=None, form=0):
     """q/k/v/out: 2-D views [tokens, ld] whose element (b, s, h, c) sits at base + b*bs + s*stride(0) + h*head_dim + c.
     Tensors may be column-offset views of a fused QKV buffer.  bias fp32 [heads, sq, sk] + gate fp32 [batch*sq, >=heads]
     add gate[b*sq+q, h] * bias[h, q, k] to the scaled scores (BEATs gated relative position bias); key_mask uint8 / bool
@@ -256,7 +256,7 @@ def attention(q, k, v, out, batch, heads, head_dim, sq, sk, scale, q_bs, k_bs, v
     d.q_bs, d.k_bs, d.v_bs, d.o_bs = q_bs, k_bs, v_bs, o_bs
     d.q_rs, d.k_rs, d.v_rs, d.o_rs = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
     d.batch, d.heads, d.head_dim, d.sq, d.sk = batch, heads, head_dim, sq, sk
-    d.scale, d.dtype = scale, _dt(q)
+    d.scale, d.dtype, d.form = scale, _dt(q), form     # form 1: the 16x16x32 kernels for every shape (tdc_attn_desc.form)
     if bias is not None:
         assert gate is not None and bias.is_cuda and gate.is_cuda and bias.dtype == gate.dtype == torch.float32
         assert bias.dim() == 3 and bias.is_contiguous() and tuple(bias.shape) == (heads, sq, sk) and sk % 4 == 0
@@ -473,6 +473,28 @@ def xattn_tile_weight(w):
     L.check(L.load().tdc_qformer_xattn_tile_weight(_ptr(w), w.stride(0), _ptr(out), _dt(w), _stream()),
             "tdc_qformer_xattn_tile_weight")
     return out
+
+
+def qformer_xattn_out(h16, h32, F, K, S, ctx, wo_t, bo, ln_g, ln_b, eps, dim, heads):
+    """The last third of the block alone (tdc_qformer_xattn with ctx): ctx [F*K, ld] = the attention output of the flat query
+    rows -> h16 / h32 query rows = LayerNorm(ctx Wo^T + bo + h)."""
+    for t in (h16, h32, ctx):
+        _chk2d(t, "xattn operand")
+    assert h32.dtype == torch.float32 and h16.dtype == wo_t.dtype == ctx.dtype
+    assert h16.shape[0] >= F * S and h32.shape[0] >= F * S and h16.stride(0) == h32.stride(0) and h16.shape[1] >= dim
+    assert ctx.shape[0] >= F * K and ctx.shape[1] >= dim and wo_t.is_cuda and wo_t.is_contiguous() and wo_t.numel() == dim * dim
+    for v in (bo, ln_g, ln_b):
+        assert v.dtype == torch.float32 and v.is_contiguous() and v.numel() >= dim
+    d = L.XattnDesc()
+    d.h16, d.h32, d.ldh = h16.data_ptr(), h32.data_ptr(), h16.stride(0)
+    d.F, d.K, d.S = F, K, S
+    d.wo, d.bo = wo_t.data_ptr(), bo.data_ptr()
+    d.ln_g, d.ln_b, d.eps = ln_g.data_ptr(), ln_b.data_ptr(), eps
+    d.dim, d.heads, d.dtype, d.Nenc = dim, heads, _dt(h16), 8
+    d.ctx, d.ldctx = ctx.data_ptr(), ctx.stride(0)
+    e0 = _prof_begin("xattn")
+    L.check(L.load().tdc_qformer_xattn(C.byref(d), _stream()), "tdc_qformer_xattn")
+    _prof_end("xattn", e0, 2.0 * F * K * dim * dim)
 
 
 def qformer_xattn(h16, h32, F, K, S, wq_t, bq, wo_t, bo, k, vt, bv, Nenc, ln_g, ln_b, eps, dim, heads, scale):

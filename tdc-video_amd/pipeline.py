@@ -18,16 +18,45 @@ from . import weights as Wt
 from .weights import pad64
 
 
+class _LRU(dict):
+    """Small bounded cache for the host-built index / mask / prompt tables (keys: geometry or prompt-id tuples): a server that
+    sees many prompts and resolutions does not grow host and device memory without bound; the least recently used entry
+    leaves when the 33rd arrives."""
+
+    def __init__(self, maxsize=32):
+        super().__init__()
+        self.maxsize = maxsize
+
+    def _touch(self, key):
+        v = dict.pop(self, key)
+        dict.__setitem__(self, key, v)          # dicts keep insertion order: the last entry is the most recent
+        return v
+
+    def get(self, key, default=None):
+        return self._touch(key) if key in self else default
+
+    def __getitem__(self, key):
+        return self._touch(key)
+
+    def __setitem__(self, key, value):
+        if key in self:
+            dict.pop(self, key)
+        dict.__setitem__(self, key, value)
+        while len(self) > self.maxsize:
+            dict.pop(self, next(iter(self)))
+
+
 class VideoEncoder:
     def __init__(self, sd, cfg, dtype=torch.float16, device="cuda", siglip_heads=16, dino_heads=24,
-                 qformer_heads=12, tower_batch=64, fp8_towers=False, tower_dtype=None):
+                 qformer_heads=12, tower_batch=64, fp8_towers=False, tower_dtype=None, ln_fuse=False):
         """sd: reference-named state dict without the leading 'model.'; cfg: dict of reference config keys.
         dtype: 16-bit type of the connector, the Q-Former and every tensor handed to the caller; tower_dtype (default:
         dtype): 16-bit type of the two ViT towers - their last kernel (the token-grid resample) writes `dtype` rows.  bf16
         towers under an fp16 connector / compressor keep the compressed tokens within 1e-3 of the fp32 reference arithmetic (measured
         1.0e-4 at full depth; all-bf16: 6e-4 ... 2e-3): the 16-bit error of the context tokens is made behind the towers.
         fp8_towers (BASELINE config 5): the towers' LayerNorms emit e4m3 rows with per-row scales and the qkv / fc1 GEMMs
-        run on fp8 operands (v_mfma_f32_16x16x128_f8f6f4); everything else stays in `tower_dtype`."""
+        run on fp8 operands (v_mfma_f32_16x16x128_f8f6f4); everything else stays in `tower_dtype`.
+        ln_fuse: the towers' pre-LayerNorms folded into the neighbouring GEMMs (weights.ln_fusion_enabled; off by default)."""
         self.cfg = dict(cfg)
         self.dtype, self.dev = dtype, torch.device(device)
         self._tower_dtype = tower_dtype = dtype if tower_dtype is None else tower_dtype
@@ -37,20 +66,22 @@ class VideoEncoder:
         d_sd = Wt._strip(sd, "vision_tower_aux_list.1.vision_tower.")
         self.towers = {}
         if s_sd:
-            self.towers["siglip"] = Wt.prep_siglip(s_sd, siglip_heads, tower_dtype, self.dev, fp8=fp8_towers)
+            self.towers["siglip"] = Wt.prep_siglip(s_sd, siglip_heads, tower_dtype, self.dev, fp8=fp8_towers, ln_fuse=ln_fuse)
         if d_sd:
-            self.towers["dino"] = Wt.prep_dino(d_sd, dino_heads, tower_dtype, self.dev, fp8=fp8_towers)
+            self.towers["dino"] = Wt.prep_dino(d_sd, dino_heads, tower_dtype, self.dev, fp8=fp8_towers, ln_fuse=ln_fuse)
         self.c = Wt.prep_connector(sd, cfg, dtype, self.dev)
         tok = cfg.get("mm_vision_tower_aux_token_len_list", [576, 576])
         self.out_grid = [int(round(t ** 0.5)) for t in tok]
         self.side = int(round(cfg.get("query_num_list", [144])[0] ** 0.5))
-        self._tables = {}
+        self._tables = _LRU(32)
         self.K = cfg.get("context_token_num", 16)
         self.H = cfg["hidden_size"]
         self.two_streams = False
         self.native_qformer = True    # Q-Former through the C++ composite tdc_qformer_fwd
-        self.fused_xattn = True       # cross-attention block of the Q-Former as one kernel per layer (tdc_qformer_xattn) when the
-                                      # shape allows it (bert-base width, K % 16 == 0, Nenc % 4 == 0, Nenc <= 224)
+        # cross-attention block of the Q-Former: 2 = one kernel per layer (tdc_qformer_xattn), 1 = q GEMM + tdc_attention,
+        # then output projection + residual + LayerNorm in one kernel, 0 = per-kernel sequence; applies when the shape allows it
+        # (bert-base width, K % 16 == 0; mode 2 also Nenc % 4 == 0, Nenc <= 224)
+        self.xattn_mode = 1
         self.native_towers = True     # towers through the C++ composite tdc_vit_fwd (per-kernel Python path when False)
         self.beats = None             # beats.BeatsEncoder for raw-waveform audio input
 
@@ -430,9 +461,10 @@ class VideoEncoder:
         S = K + Lt
         h32, h16 = ops.qformer_embed(query, qsrc, qf.word, qf.pos, ids, qf.emb_ln[0], qf.emb_ln[1], 1e-12, F, K, Dq, dt)
         # the cross-attention block: fused form = key GEMM + transposed value GEMM + one kernel per cross layer
-        fused = (getattr(self, "fused_xattn", True) and qf.cross_k is not None
-                 and ops.qformer_xattn_supported(Dq, heads, K, Nenc))
-        if fused:
+        mode = int(getattr(self, "xattn_mode", 1)) if qf.cross_k is not None else 0
+        fused = mode >= 2 and ops.qformer_xattn_supported(Dq, heads, K, Nenc)
+        out_fused = not fused and mode >= 1 and ops.qformer_xattn_supported(Dq, heads, K, 8)
+        if fused or out_fused:
             self._tile_cross_weights()
         ops.TAG = "xattn_block"
         if fused:
@@ -470,9 +502,13 @@ class VideoEncoder:
                 ldk = kv_all.stride(0)
                 ops.attention(cq[:, :Dq], kk, vv, ctx_q, F, heads, hd, K, Nenc, scale, K * cq.stride(0), Nenc * ldk,
                               Nenc * ldk, K * ctx_q.stride(0))
-                ops.gemm(ctx_q, Lr.cross.out.w, Lr.cross.out.b, res=h32, r_map=qmap, out=t32, out_f32=True, M=F * K)
-                ops.layernorm(t32, Lr.cross.ln[0], Lr.cross.ln[1], 1e-12, Dq, dt, y16=h16, y32=h32, rows=F * K,
-                              y_map=qmap)
+                if out_fused:
+                    ops.qformer_xattn_out(h16, h32, F, K, S, ctx_q, Lr.cross.out_tiled, Lr.cross.out.b, Lr.cross.ln[0],
+                                          Lr.cross.ln[1], 1e-12, Dq, heads)
+                else:
+                    ops.gemm(ctx_q, Lr.cross.out.w, Lr.cross.out.b, res=h32, r_map=qmap, out=t32, out_f32=True, M=F * K)
+                    ops.layernorm(t32, Lr.cross.ln[0], Lr.cross.ln[1], 1e-12, Dq, dt, y16=h16, y32=h32, rows=F * K,
+                                  y_map=qmap)
             ops.TAG = None
             m = ops.gemm(h16, Lr.ffn_q.fc1.w, Lr.ffn_q.fc1.b, act=L.ACT_GELU_ERF, M=F * K, a_map=qmap)
             ops.gemm(m, Lr.ffn_q.fc2.w, Lr.ffn_q.fc2.b, res=h32, r_map=qmap, out=t32, out_f32=True, M=F * K)
@@ -596,7 +632,7 @@ class VideoEncoder:
 
     def _qformer_struct(self):
         """ctypes mirror of tdc_qformer_model (cached)."""
-        fused_on = bool(getattr(self, "fused_xattn", True))
+        fused_on = int(getattr(self, "xattn_mode", 1))
         if getattr(self, "_qf_struct", None) is not None and self._qf_struct[2] == fused_on:
             return self._qf_struct
         c, qf = self.c, self.c.qformer
@@ -629,8 +665,9 @@ class VideoEncoder:
         m.word, m.pos, m.ldw = qf.word.data_ptr(), qf.pos.data_ptr(), qf.word.stride(0)
         m.emb_ln_g, m.emb_ln_b = qf.emb_ln[0].data_ptr(), qf.emb_ln[1].data_ptr()
         m.cross_kv, m.vision_proj = lin(qf.cross_kv), lin(c.vision_proj)
-        if qf.cross_k is not None and getattr(self, "fused_xattn", True):
+        if qf.cross_k is not None:
             m.cross_k, m.cross_v, m.cross_bv = lin(qf.cross_k), lin(qf.cross_v), qf.cross_bv.data_ptr()
+            m.xattn_mode = fused_on
         m.layers_host = layers
         self._qf_struct = (m, layers, fused_on)
         return self._qf_struct

@@ -158,7 +158,9 @@ def emit_plan(T, N, K, seg_indices, max_visual_len, add_static=True):
         kinds = [k[:-rm] for k in kinds]
         aa = [a[:-rm] for a in aa]
         bb = [b[:-rm] for b in bb]
-    cat = lambda xs: (np.concatenate(xs) if xs else np.zeros(0, dtype=np.int64))[:max(0, max_visual_len)]
+    # python slice semantics as in the reference (cambrian_arch.py:1709, new_visual_emb_frames[:max_visual_len]): a NEGATIVE
+    # budget (text longer than the model length) drops the last |budget| tokens, it does not empty the stream
+    cat = lambda xs: (np.concatenate(xs) if xs else np.zeros(0, dtype=np.int64))[:max_visual_len]
     plan = Plan(chunks=chunks, comp_frames=comp_frames, comp_chunk=comp_chunk, key_frames=key_frames)
     plan.kind, plan.a, plan.b = cat(kinds), cat(aa), cat(bb)
     plan.a = np.where(plan.kind == 2, 0, plan.a)

@@ -117,13 +117,13 @@ def fold_c1(lin):
     return lin.w.float().sum(1).contiguous()
 
 
-def ln_fusion_enabled(dim):
-    """TDC_LN_FUSE=1: the towers fold their pre-LayerNorms into the neighbouring GEMMs (widths that are a whole number
-    of 64-column slots).  Off by default: measured neutral on MI355X (+0.4 % frames/s) - the fold
-    moves the LayerNorm's bytes (an HBM-bound kernel at 5.3 TB/s) into the GEMM epilogue, which is bound by the
-    16 B/clk store path of a CU; it pays once that drain is overlapped with MFMA work."""
-    import os
-    return dim % 64 == 0 and os.environ.get("TDC_LN_FUSE", "0") == "1"
+def ln_fusion_enabled(dim, requested=False):
+    """LayerNorm fusion of the towers (VideoEncoder(ln_fuse=True); no environment variable): the pre-LayerNorms fold into the
+    neighbouring GEMMs (widths that are a whole number of 64-column slots).  Off by default: measured neutral on MI355X
+     - the fold moves the LayerNorm's bytes (an HBM-bound kernel at 6 TB/s) into the GEMM epilogue, which
+    is not overlapped with MFMA work; the LayerNorm kernel is also the path with the larger numerical margin.  Kept as a
+    tested alternative (bit-identical statistics whichever GEMM kernel computes a row), not as a tuning knob."""
+    return dim % 64 == 0 and bool(requested)
 
 
 def vec32(v, dev, n_pad=None, fill=0.0):
@@ -174,14 +174,14 @@ def _strip(sd, prefix):
 
 
 # ---------------------------------------------------------------------------------------------------- towers
-def prep_siglip(sd, heads, dtype, dev, patch=14, eps=1e-6, fp8=False):
+def prep_siglip(sd, heads, dtype, dev, patch=14, eps=1e-6, fp8=False, ln_fuse=False):
     """sd: HF SiglipVisionModel state dict (4.46 'vision_model.' prefix accepted).  siglip_encoder.py:71-78."""
     sd = {k.replace("vision_model.", ""): v for k, v in sd.items()}
     Wp = sd["embeddings.patch_embedding.weight"]
     D = Wp.shape[0]
     t = Namespace(kind="siglip", dim=D, heads=heads, head_dim=D // heads, patch=patch, eps=eps, has_cls=0,
                   act="gelu_tanh", final_ln=None, fp8=fp8_enabled(D, fp8))
-    t.fused = ln_fusion_enabled(D) and not t.fp8
+    t.fused = ln_fusion_enabled(D, ln_fuse) and not t.fp8
     t.patch_lin = make_lin(Wp.reshape(D, -1), sd["embeddings.patch_embedding.bias"], dtype, dev)
     t.pos_table = sd["embeddings.position_embedding.weight"].detach().float().cpu()  # [P, D]
     t.layers = []
@@ -214,13 +214,13 @@ def prep_siglip(sd, heads, dtype, dev, patch=14, eps=1e-6, fp8=False):
     return t
 
 
-def prep_dino(sd, heads, dtype, dev, patch=14, eps=1e-6, fp8=False):
+def prep_dino(sd, heads, dtype, dev, patch=14, eps=1e-6, fp8=False, ln_fuse=False):
     """sd: HF Dinov2Model state dict.  dino_encoder.py:109-120."""
     Wp = sd["embeddings.patch_embeddings.projection.weight"]
     D = Wp.shape[0]
     t = Namespace(kind="dino", dim=D, heads=heads, head_dim=D // heads, patch=patch, eps=eps, has_cls=1,
                   act="swiglu", fp8=fp8_enabled(D, fp8))
-    t.fused = ln_fusion_enabled(D) and not t.fp8
+    t.fused = ln_fusion_enabled(D, ln_fuse) and not t.fp8
     t.patch_lin = make_lin(Wp.reshape(D, -1), sd["embeddings.patch_embeddings.projection.bias"], dtype, dev)
     t.pos_table = sd["embeddings.position_embeddings"].detach().float().cpu()[0]  # [1+n*n, D]
     t.cls = sd["embeddings.cls_token"].detach().float().cpu().flatten()

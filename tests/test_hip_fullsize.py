@@ -152,8 +152,8 @@ def test_fullsize_towers_vs_oracle(full_sd, dtype, tol, fuse, monkeypatch):
     from tdc_video_amd.pipeline import VideoEncoder
     orc = _oracle()
     sd, cfg, H, K = full_sd
-    monkeypatch.setenv("TDC_LN_FUSE", fuse)     # "1": pre-LayerNorms folded into the neighbouring GEMMs
-    enc = VideoEncoder(sd, cfg, dtype=dtype, device="cuda:0", tower_batch=2)
+    # fuse "1": pre-LayerNorms folded into the neighbouring GEMMs
+    enc = VideoEncoder(sd, cfg, dtype=dtype, device="cuda:0", tower_batch=2, ln_fuse=fuse == "1")
     g = torch.Generator().manual_seed(5)
     xs = torch.rand(2, 3, 384, 384, generator=g) * 2 - 1
     xd = torch.rand(2, 3, 378, 378, generator=g) * 2 - 1
@@ -260,7 +260,7 @@ def test_fullsize_video_plus_audio_token_accounting(full):
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 8e-3), (torch.bfloat16, 6e-2)])
 def test_fullsize_ln_fusion_matches_layernorm_kernel(full_sd, dtype, tol, monkeypatch):
-    """TDC_LN_FUSE=1 (pre-LayerNorms folded into the neighbouring GEMMs: 16-bit row copy + per-slot statistics out of the
+    """VideoEncoder(ln_fuse=True) (pre-LayerNorms folded into the neighbouring GEMMs: 16-bit row copy + per-slot statistics out of the
     residual-stream GEMM, (mean, rstd) folded into the next GEMM's epilogue) against the LayerNorm-kernel path, both
     towers at full depth / width; and the fused path is batch invariant bit for bit like everything else."""
     import bench
@@ -271,8 +271,7 @@ def test_fullsize_ln_fusion_matches_layernorm_kernel(full_sd, dtype, tol, monkey
     vd = bench.synth_video(0, 3, 378, "cuda:0", dtype, seed=4321)
     outs = {}
     for fuse in ("0", "1"):
-        monkeypatch.setenv("TDC_LN_FUSE", fuse)
-        enc = VideoEncoder(sd, cfg, dtype=dtype, device="cuda:0", tower_batch=3)
+        enc = VideoEncoder(sd, cfg, dtype=dtype, device="cuda:0", tower_batch=3, ln_fuse=fuse == "1")
         assert all(bool(t.fused) == (fuse == "1") for t in enc.towers.values())
         outs[fuse] = (enc.tower("siglip", vs).float(), enc.tower("dino", vd).float())
         if fuse == "1":

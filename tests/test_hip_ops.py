@@ -382,24 +382,23 @@ def test_attention_integer_layout(ops):
 
 
 @pytest.mark.parametrize("d,S", [(64, 320), (72, 300), (64, 729), (72, 577)])
-def test_attention32_layout_and_agreement_with_the_16x16_form(ops, d, S, monkeypatch):
+def test_attention32_layout_and_agreement_with_the_16x16_form(ops, d, S):
     """The 32x32x16 form (attention32.hip: long sequences, head dim 64 / 72): integer-valued V under uniform and under
     one-hot attention catches a wrong key permutation between the S accumulator and the transposed V reads, a wrong
-    output-column map or a wrong LDS swizzle; random data must agree with the 16x16x32 form (TDC_ATTN32=0) to rounding."""
+    output-column map or a wrong LDS swizzle; random data must agree with the 16x16x32 form (tdc_attn_desc.form = 1) to rounding."""
     B, H = 2, 3
     D = H * d
     ld = ops.pad64(D)
 
-    def run(q, k, v):
+    def run(q, k, v, form=0):
         out = torch.zeros(B * S, ld, device="cuda", dtype=q.dtype)
-        ops.attention(q[:, :D], k[:, :D], v[:, :D], out, B, H, d, S, S, 1.0, S * ld, S * ld, S * ld, S * ld)
+        ops.attention(q[:, :D], k[:, :D], v[:, :D], out, B, H, d, S, S, 1.0, S * ld, S * ld, S * ld, S * ld, form=form)
         return out[:, :D].float()
     z = torch.zeros(B * S, ld, device="cuda", dtype=torch.float16)
     rows = torch.arange(B * S, device="cuda").view(-1, 1)
     cols = torch.arange(D, device="cuda").view(1, -1)
     v = torch.zeros_like(z)
     v[:, :D] = ((rows * 7 + cols * 3) % 13).half()
-    monkeypatch.setenv("TDC_ATTN32", "1")
     # uniform attention: every output row is the mean of its batch item's V
     got = run(z, z, v)
     ref = v[:, :D].float().view(B, S, D).mean(1, keepdim=True).expand(B, S, D).reshape(B * S, D)
@@ -423,9 +422,7 @@ def test_attention32_layout_and_agreement_with_the_16x16_form(ops, d, S, monkeyp
     for dtype in DT:
         qkv = [torch.randn(B * S, ld, device="cuda", generator=g).to(dtype) for _ in range(3)]
         a = run(*qkv)
-        monkeypatch.setenv("TDC_ATTN32", "0")
-        b = run(*qkv)
-        monkeypatch.setenv("TDC_ATTN32", "1")
+        b = run(*qkv, form=1)
         assert (a - b).abs().max().item() < (4e-3 if dtype == torch.float16 else 3e-2)
         assert not torch.equal(a, b) or True
 
@@ -564,3 +561,29 @@ def test_qformer_xattn_fused_block(ops, dtype, F, K, Lt, Nenc):
     other[rows] = False
     assert torch.equal(h16[other], ref16[other]) and torch.equal(h32[other], ref32[other])
     assert not ops.qformer_xattn_supported(64, 4, 4, 16) and ops.qformer_xattn_supported(768, 12, 144, 156)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("F,K,Lt", [(5, 144, 12), (9, 16, 0)])
+def test_qformer_xattn_output_projection_only(ops, dtype, F, K, Lt):
+    """tdc_qformer_xattn with ctx: LayerNorm(ctx Wo^T + bo + h) on the K query rows of every frame (BertSelfOutput,
+    tdc/Qformer.py:285-289) against torch fp32; text rows untouched; a ragged last 64-row block."""
+    D, heads = 768, 12
+    S = K + Lt
+    g = torch.Generator().manual_seed(F + K)
+    dev = "cuda"
+    h16 = torch.randn(F * S, D, generator=g).to(dtype).to(dev)
+    h32 = h16.float().clone()
+    ctx = torch.randn(F * K, D, generator=g).to(dtype).to(dev)
+    wo = (torch.randn(D, D, generator=g) * 0.05).to(dtype).to(dev)
+    bo = (torch.randn(D, generator=g) * 0.1).to(dev)
+    ln_g, ln_b = (1 + 0.1 * torch.randn(D, generator=g)).to(dev), (0.1 * torch.randn(D, generator=g)).to(dev)
+    ref16, ref32 = h16.clone(), h32.clone()
+    ops.qformer_xattn_out(h16, h32, F, K, S, ctx, ops.xattn_tile_weight(wo), bo, ln_g, ln_b, 1e-12, D, heads)
+    rows = (torch.arange(F, device=dev)[:, None] * S + torch.arange(K, device=dev)[None, :]).reshape(-1)
+    y = torch.nn.functional.layer_norm(ctx.float() @ wo.float().t() + bo + ref32[rows], (D,), ln_g, ln_b, 1e-12)
+    assert (h32[rows] - y).abs().max().item() < (2e-3 if dtype == torch.float16 else 1.5e-2)
+    assert torch.equal(h16[rows], h32[rows].to(dtype))
+    other = torch.ones(F * S, dtype=torch.bool, device=dev)
+    other[rows] = False
+    assert torch.equal(h16[other], ref16[other]) and torch.equal(h32[other], ref32[other])

@@ -118,8 +118,7 @@ def _rand_tower_sd(kind, D, heads, mlp, layers, grid_in, g, std=0.05):
                                                        ("siglip", 192, 3, 400, 126, "1")])
 def test_towers_natural_scale(kind, D, heads, mlp, px, fuse, dtype, monkeypatch):
     """Real head dims (72: the padded-to-96 MFMA path, 64) at trained-model-like scales, HIP vs oracle; fuse = "1": the
-    pre-LayerNorms folded into the neighbouring GEMMs (TDC_LN_FUSE, widths that are multiples of 64)."""
-    monkeypatch.setenv("TDC_LN_FUSE", fuse)
+    pre-LayerNorms folded into the neighbouring GEMMs (ln_fuse, widths that are multiples of 64)."""
     import tdc_video_amd  # noqa: F401
     from tdc_video_amd import weights as Wt
     from tdc_video_amd.pipeline import VideoEncoder
@@ -134,7 +133,7 @@ def test_towers_natural_scale(kind, D, heads, mlp, px, fuse, dtype, monkeypatch)
     enc.dtype, enc.dev, enc.tower_batch = dtype, torch.device("cuda"), 2   # exercises the batch loop too
     enc._tables = {}
     enc.out_grid = [out_grid, out_grid]
-    t = (Wt.prep_siglip if kind == "siglip" else Wt.prep_dino)(sd, heads, dtype, enc.dev)
+    t = (Wt.prep_siglip if kind == "siglip" else Wt.prep_dino)(sd, heads, dtype, enc.dev, ln_fuse=fuse == "1")
     enc.towers = {kind: t}
     out = enc.tower(kind, pixels.cuda())
     got = out[:, :D].reshape(5, out_grid * out_grid, D)
@@ -478,7 +477,6 @@ def test_raw_waveform_audio_through_beats_vs_oracle():
 def test_native_tower_composite_equals_kernel_sequence(dtype, fuse, monkeypatch):
     """tdc_vit_fwd (C++ composite) launches the same kernels as the per-kernel Python sequence: bit-identical output
     (fuse = "1": with the LayerNorm fusion; the DINO fixture is 64 wide, the 48-wide SigLIP one stays unfused)."""
-    monkeypatch.setenv("TDC_LN_FUSE", fuse)
     import tdc_video_amd  # noqa: F401
     from tdc_video_amd import weights as Wt
     from tdc_video_amd.pipeline import VideoEncoder
@@ -488,7 +486,7 @@ def test_native_tower_composite_equals_kernel_sequence(dtype, fuse, monkeypatch)
         enc.dtype, enc.dev, enc.tower_batch = dtype, torch.device("cuda"), 2
         enc._tables = {}
         enc.out_grid = [8, 8]
-        enc.towers = {prep: (Wt.prep_siglip if prep == "siglip" else Wt.prep_dino)(W, 4, dtype, enc.dev)}
+        enc.towers = {prep: (Wt.prep_siglip if prep == "siglip" else Wt.prep_dino)(W, 4, dtype, enc.dev, ln_fuse=fuse == "1")}
         px = torch.from_numpy(o["pixels"]).cuda()
         enc.native_towers = True
         a = enc.tower(prep, px)

@@ -88,7 +88,9 @@ def test_emit_plan_layout_and_clipping():
     assert plan["comp_frames"] == [f for s, e in chunks for f in range(s + 1, e)]
     assert plan["key_frames"] == [s for s, e in chunks if e - s > 1]
     # clipping reproduces tdc/cambrian_arch.py:1694-1709 on a token-id model of the stream
-    for budget in (500, 333, 100, 7):
+    # ... incl. a zero and NEGATIVE budgets (text longer than the model length): the reference's python slices then drop the
+    # last |budget| tokens of what the per-chunk clipping left (cambrian_arch.py:1709)
+    for budget in (500, 333, 100, 7, 0, -3, -40):
         ids_per_chunk = []
         for (s, e) in chunks:
             t = [("f", s, i) for i in range(N)] + [("s",)]
@@ -254,8 +256,6 @@ def test_weight_prep_layernorm_fold_and_fp8(monkeypatch):
     assert (deq - lin16.w.float()).abs().max().item() <= lin16.w.float().abs().max().item() * 2 ** -4
     assert abs(deq.abs().max().item() - lin16.w.float().abs().max().item()) < 1e-6
     # switches: fusion needs whole 64-column slots, fp8 whole 128-byte K tiles, and fp8 excludes the fusion
-    monkeypatch.setenv("TDC_LN_FUSE", "1")
-    assert Wt.ln_fusion_enabled(1152) and not Wt.ln_fusion_enabled(48)
+    assert Wt.ln_fusion_enabled(1152, True) and not Wt.ln_fusion_enabled(48, True)
     assert Wt.fp8_enabled(1536, True) and not Wt.fp8_enabled(1152 + 64, True) and not Wt.fp8_enabled(1536, False)
-    monkeypatch.delenv("TDC_LN_FUSE")
     assert not Wt.ln_fusion_enabled(1152)

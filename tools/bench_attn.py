@@ -21,11 +21,9 @@ def main():
         ld = ops.pad64(3 * D)
         qkv = torch.randn(B * S, ld, device="cuda", generator=g).to(dtype)
         out = torch.empty(B * S, ops.pad64(D), device="cuda", dtype=dtype)
-        fn = lambda: ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], out, B, H, d, S, S,
-                                   1 / math.sqrt(d), S * ld, S * ld, S * ld, S * out.stride(0))
-        os.environ["TDC_ATTN32"] = "0"
-        ms16 = timeit(fn)
-        os.environ["TDC_ATTN32"] = "1"
+        fn = lambda form=0: ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], out, B, H, d, S, S,
+                                          1 / math.sqrt(d), S * ld, S * ld, S * ld, S * out.stride(0), form=form)
+        ms16 = timeit(lambda: fn(1))
         ms = timeit(fn)
         q, k, v = (qkv[: 2 * S, i * D:(i + 1) * D].float().view(2, S, H, d).transpose(1, 2) for i in range(3))
         ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(2 * S, D)

@@ -35,7 +35,9 @@ int main(int argc, char** argv) {
             printf("skip M=%d N=%d K=%d (not an fp8 tower shape)\n", M, N, K);
             continue;
         }
-        size_t nA = (size_t)M * K, nW = (size_t)N * K, nC = (size_t)M * N;
+        const bool pad8 = (N % 8 == 4) && !res && !outf32 && act == TDC_ACT_NONE && !fp8;   // the transposed value projection of the Q-Former
+        const int ldc_full = pad8 ? (N + 7) / 8 * 8 : N;
+        size_t nA = (size_t)M * K, nW = (size_t)N * K, nC = (size_t)M * ldc_full;
         std::vector<unsigned short> hA(nA), hW(nW);
         fill_bf16(hA, M + K, 1.0f); fill_bf16(hW, N + K, 0.05f);
         void *A, *W, *C; float* bias;
@@ -48,7 +50,8 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(A, hA.data(), nA * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(W, hW.data(), nW * 2, hipMemcpyHostToDevice));
         CK(hipMemset(bias, 0, N * 4)); CK(hipMemset(C, 0, nC * (outf32 ? 4 : 2)));
         tdc_gemm_desc d = {};
-        d.A = A; d.lda = K; d.W = W; d.ldw = K; d.C = C; d.ldc = (act == TDC_ACT_SWIGLU) ? N / 2 : N; d.bias = bias;
+        d.A = A; d.lda = K; d.W = W; d.ldw = K; d.C = C; d.ldc = (act == TDC_ACT_SWIGLU) ? N / 2 : ldc_full; d.bias = pad8 ? nullptr : bias;
+        d.c_pad8 = pad8 ? 1 : 0;
         d.M = M; d.N = N; d.K = K; d.dtype = TDC_BF16; d.out_f32 = outf32; d.act = act;
         if (res) { d.res = C; d.ldres = N; d.res_f32 = outf32; }   // in-place residual stream update
         float *stats = nullptr, *c1 = nullptr;

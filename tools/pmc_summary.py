@@ -17,11 +17,32 @@ def per_dispatch(counter):
     return [float(r["Counter_Value"]) for r in rows]
 
 
-fetch, write = per_dispatch("FETCH_SIZE"), per_dispatch("WRITE_SIZE")
+def n_dispatches(shape):
+    """kernel launches tdc_gemm makes for one call (csrc/gemm.hip): N = 256 t + 128 goes out as the 256 x 256 kernel on the first
+    256 t columns + the 128 x 128 kernel on the last 128"""
+    M, N, K, act, has_res, of32, count = shape
+    fp8 = bool(os.environ.get("TDC_PMC_FP8"))
+    split = (not fp8 and N % 256 == 128 and N >= 640 and ((M + 255) // 256) * (N // 256) >= 192 and K >= 128 and act != 3)
+    return 2 if split else 1
+
+
+def fold(values):
+    """per-dispatch counter values -> one value per shape (the launches of a split call summed)"""
+    out_, i = [], 0
+    for shp in shapes:
+        n = n_dispatches(shp)
+        out_.append(sum(values[i:i + n]))
+        i += n
+    assert i == len(values), (i, len(values))
+    return out_
+
+
+import os
+fetch, write = fold(per_dispatch("FETCH_SIZE")), fold(per_dispatch("WRITE_SIZE"))
 assert len(fetch) == len(shapes) == len(write), (len(fetch), len(write), len(shapes))
 try:    # MFMA pipe occupancy: busy cycles summed over the 1024 SIMDs / (1024 x kernel cycles); GRBM_GUI_ACTIVE is summed
     # over the 8 XCDs (MI355X_MICROARCH.md, DVFS).  16 busy cycles per v_mfma_f32_16x16x32 (its pipe time).
-    mfma, gui = per_dispatch("SQ_VALU_MFMA_BUSY_CYCLES"), per_dispatch("GRBM_GUI_ACTIVE")
+    mfma, gui = fold(per_dispatch("SQ_VALU_MFMA_BUSY_CYCLES")), fold(per_dispatch("GRBM_GUI_ACTIVE"))
     assert len(mfma) == len(gui) == len(shapes)
 except Exception as e:  # noqa: BLE001
     print("no MFMA-busy pass:", e)
