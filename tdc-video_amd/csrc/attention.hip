@@ -322,6 +322,12 @@ int launch_qt(const AttnArgs& a, int batch, hipStream_t st) {
     if (DK == 64 && !BIAS && a.sq > 256) {
         dim3 grid((a.sq + 255) / 256, a.heads, batch);
         hipLaunchKernelGGL((attn_kernel<T, DK, NDV, 4, VEC, BIAS>), grid, dim3(256), 0, st, a);
+    } else if (DK == 64 && !BIAS && a.sq > 128 && a.sq <= 192) {
+        // 129 ... 192 query rows (the Q-Former's K = 144 queries against a frame's tokens): ONE workgroup per (batch, head) with 48
+        // rows per wave - 144 rows are exactly three waves' worth - instead of two 128-row workgroups that stage the same K / V
+        // twice, the second one for 16 rows
+        dim3 grid(1, a.heads, batch);
+        hipLaunchKernelGGL((attn_kernel<T, DK, NDV, 3, VEC, BIAS>), grid, dim3(256), 0, st, a);
     } else if (a.sq > 64) {
         dim3 grid((a.sq + 127) / 128, a.heads, batch);
         hipLaunchKernelGGL((attn_kernel<T, DK, NDV, 2, VEC, BIAS>), grid, dim3(256), 0, st, a);

@@ -72,24 +72,9 @@ extern "C" int tdc_gemm(const tdc_gemm_desc* d, void* stream) {
     }
     if (d->in_fp8) return tdc_gemm_fp8_impl(d, st);
     if (d->dtype != TDC_F16 && d->dtype != TDC_BF16) return TDC_E_BADARG;
-    // N = 256 t + 128 (SigLIP's 1152-wide out-projection and fc2: 113 ms of a 1.2-s step): the last column tile of the 256 x 256
-    // kernel would be half empty - two of its four wave columns only stage - i.e. 1 / (2 t + 1) of the launch's MFMA time idle.
-    // The last 128 columns go to the 128 x 128 kernel as a launch of their own (column-offset views of W / bias / C / res): every
-    // output element is computed by exactly one of the two launches, with the same K order as ever.
-    if (d->N % 256 == 128 && d->N >= 640 && (long long)((d->M + 255) / 256) * (d->N / 256) >= 192 && d->K >= 128 &&
-        d->act != TDC_ACT_SWIGLU && !d->x16 && !d->ln_stats && !d->out_fp8 && !d->c_pad8) {
-        tdc_gemm_desc a = *d, b = *d;
-        const int n1 = d->N - 128;
-        a.N = n1;
-        b.N = 128;
-        b.W = (const char*)d->W + (size_t)n1 * d->ldw * 2;
-        b.C = (char*)d->C + (size_t)n1 * (d->out_f32 ? 4 : 2);
-        if (d->bias) b.bias = d->bias + n1;
-        if (d->res) b.res = (const char*)d->res + (size_t)n1 * (d->res_f32 ? 4 : 2);
-        const int rc = d->dtype == TDC_F16 ? launch<f16, false>(&a, st) : launch<bf16, false>(&a, st);
-        if (rc) return rc;
-        return d->dtype == TDC_F16 ? launch<f16, false>(&b, st, true) : launch<bf16, false>(&b, st, true);
-    }
+    // (Round 3 tried sending the last 128 columns of an N = 256 t + 128 GEMM - SigLIP's 1152-wide out-projection and fc2, whose
+    // fifth column tile is half empty - to the 128 x 128 kernel as a launch of its own: 7-10 % SLOWER on both shapes; the second
+    // launch streams the whole A operand again for an eighth of the columns.  Removed.)
     if (d->dtype == TDC_F16) return launch<f16, false>(d, st);
     return launch<bf16, false>(d, st);
 }

@@ -332,7 +332,9 @@ def _attn_ref(q, k, v, scale):
 @pytest.mark.parametrize("B,H,d,sq,sk", [(2, 3, 64, 200, 200), (1, 2, 72, 729, 729), (2, 4, 64, 730, 730),
                                          (3, 12, 64, 16, 156), (2, 12, 64, 28, 28), (2, 4, 12, 81, 81),
                                          (2, 4, 16, 82, 82), (3, 2, 64, 144, 206), (1, 16, 72, 576, 576),
-                                         (1, 3, 64, 300, 300), (2, 2, 64, 257, 130)])     # 64-row-per-wave form, ragged
+                                         (1, 3, 64, 300, 300), (2, 2, 64, 257, 130),      # 64-row-per-wave form, ragged
+                                         (3, 12, 64, 144, 156), (2, 3, 64, 156, 156), (2, 2, 64, 129, 70),
+                                         (1, 2, 64, 192, 64)])                            # 48-row-per-wave form (129 ... 192 rows)
 def test_attention(ops, dtype, B, H, d, sq, sk):
     g = torch.Generator(device="cuda").manual_seed(4)
     D = H * d

@@ -22,8 +22,7 @@ def n_dispatches(shape):
     256 t columns + the 128 x 128 kernel on the last 128"""
     M, N, K, act, has_res, of32, count = shape
     fp8 = bool(os.environ.get("TDC_PMC_FP8"))
-    split = (not fp8 and N % 256 == 128 and N >= 640 and ((M + 255) // 256) * (N // 256) >= 192 and K >= 128 and act != 3)
-    return 2 if split else 1
+    return 1    # (round 3's column split of N = 256 t + 128 was removed again: one launch per call)
 
 
 def fold(values):
