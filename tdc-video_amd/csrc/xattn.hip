@@ -32,9 +32,8 @@
 #include <type_traits>
 
 // XATTN_DIAG (tools/xattn_diag.py only, never the library build): bit mask of pieces left out for timing - 1 = the q-proj
-// MFMA loop, 2 = the attention phase, 4 = the out-proj MFMA loop, 8 = the final stores; inside the attention phase 16 = the
-// inside the attention phase 16 = consumer waves idle (barriers only), 32 = loader waves request nothing.  Results are then
-// wrong by design.
+// MFMA loop, 2 = the attention phase, 4 = the out-proj MFMA loop, 8 = the final stores, 128 = the staging loads; inside the
+// attention phase 16 = consumer waves idle (barriers only), 32 = loader waves request nothing.  Results are then wrong by design.
 #ifndef XATTN_DIAG
 #define XATTN_DIAG 0
 #endif
@@ -185,6 +184,7 @@ __global__ __launch_bounds__(512, 2) void xattn_kernel(XattnArgs p) {
             int flat = r0 + row;
             if (flat > p.rows - 1) flat = p.rows - 1;
             const long long src = OUT_ONLY ? (long long)flat * p.ldctx : (long long)grow_of(flat, p.K, p.S, p.invK) * p.ldh;
+            if (XATTN_DIAG & 128) continue;
             const v8 v = *(const v8*)(H + src + ch * 8);
             *(v8*)(buf + buf_off(row, ch * 8)) = v;
         }

@@ -1,6 +1,7 @@
 """The Q-Former cross-attention BLOCK at the bench's size, fused against un-fused, bf16 / fp16, one MI355X:
   fused    key GEMM [F*N, 4608] + transposed value GEMM [4608, F*N] + 6 x tdc_qformer_xattn
   un-fused stacked K/V GEMM [F*N, 9216] + 6 x {q GEMM, tdc_attention, dense GEMM (fp32 residual), tdc_layernorm}
+  out-fused (the default, xattn_mode 1) stacked K/V GEMM + 6 x {q GEMM, tdc_attention, tdc_qformer_xattn in its ctx form}
 Algorithmic work: 12.76 GFLOP per compressed frame at K = 144, N = 156, H = 3584.
 usage: python tools/bench_xattn.py [F=439] [K=144] [N=156] [dtype=fp16]"""
 import os
@@ -65,6 +66,24 @@ def unfused():
         ops.layernorm(t32, ln_g, ln_b, 1e-12, D, dt, y16=h16, y32=h32, rows=F * K, y_map=qmap)
 
 
+def out_fused(ev=None):
+    """the default form (xattn_mode 1): q GEMM and tdc_attention as launches, output projection + residual + LayerNorm fused"""
+    def t(kind, fn):
+        if ev is None:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); r = fn(); e1.record()
+        ev.append((kind, e0, e1))
+        return r
+    kv = t("kv gemm", lambda: ops.gemm(enc, wkv, bkv))
+    ld = kv.stride(0)
+    for j in range(NL):
+        cq = t("q gemm", lambda: ops.gemm(h16, wq[j], bq, M=F * K, a_map=qmap))
+        t("attention", lambda: ops.attention(cq, kv[:, j * 2 * D:j * 2 * D + D], kv[:, j * 2 * D + D:(j + 1) * 2 * D], ctxq, F, heads,
+                                             64, K, N, 0.125, K * cq.stride(0), N * ld, N * ld, K * ctxq.stride(0)))
+        t("out kernel", lambda: ops.qformer_xattn_out(h16, h32, F, K, S, ctxq, wo_t[j], bo, ln_g, ln_b, 1e-12, D, heads))
+
+
 def parts():
     """per-kernel times of the fused form"""
     ev = []
@@ -84,7 +103,7 @@ def parts():
 
 
 flop = F * (2.0 * N * H * 2 * D * NL + NL * (4.0 * K * D * D + 4.0 * K * N * D))
-for name, fn in (("fused", fused), ("un-fused", unfused)):
+for name, fn in (("fused", fused), ("un-fused", unfused), ("out-fused", out_fused)):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -98,3 +117,10 @@ for name, fn in (("fused", fused), ("un-fused", unfused)):
           % (name, F, K, N, str(dt)[6:], ms, flop / ms / 1e9, flop / ms / 1e9 / 25.0, flop / F / 1e9), flush=True)
 p = parts()
 print("fused parts: key GEMM %.3f ms, value^T GEMM %.3f ms, xattn kernel %s ms" % (p[0], p[1], " ".join("%.3f" % x for x in p[2:])))
+ev = []
+out_fused(ev)
+torch.cuda.synchronize()
+by = {}
+for kind, a, b in ev:
+    by.setdefault(kind, []).append(a.elapsed_time(b))
+print("out-fused parts: " + ", ".join("%s %s ms" % (k, " ".join("%.3f" % x for x in v)) for k, v in by.items()))

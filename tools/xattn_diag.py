@@ -1,6 +1,6 @@
 """Where does tdc_qformer_xattn spend its time?  Builds csrc/xattn.hip with -DXATTN_DIAG=<mask> (pieces left out: 1 = q-proj
-MFMA loop, 2 = attention phase, 4 = out-proj MFMA loop, 8 = final stores) into scratch libraries and times the same launch
-through each.  GPU box:  python tools/xattn_diag.py [masks...] > gpurun_out/xattn_diag.log"""
+MFMA loop, 2 = attention phase, 4 = out-proj MFMA loop, 8 = final stores, 128 = no staging loads) into scratch libraries and times the same launch
+through each.  GPU box:  python tools/xattn_diag.py [--out-only] [masks...] > gpurun_out/xattn_diag.log"""
 import ctypes as C
 import os
 import subprocess
@@ -13,7 +13,8 @@ sys.path.insert(0, ROOT)
 import tdc_video_amd  # noqa: F401,E402
 from tdc_video_amd import lib as L, ops  # noqa: E402
 
-masks = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 4, 7, 15]
+OUT = "--out-only" in sys.argv      # time the ctx form (output projection + residual + LayerNorm alone)
+masks = [int(a) for a in sys.argv[1:] if a != "--out-only"] or [0, 1, 2, 4, 7, 15]
 F, K, N, D, heads, Lt = 439, 144, 156, 768, 12, 12
 S = K + Lt
 dt, dev = torch.float16, "cuda"
@@ -25,6 +26,7 @@ bq, bo, bv = rnd(D, sc=0.02), rnd(D, sc=0.02), rnd(D, sc=0.02)
 ln_g, ln_b = torch.ones(D, device=dev), torch.zeros(D, device=dev)
 k = rnd(F * N, D).to(dt)
 vt = rnd(D, ops.pad64(F * N)).to(dt)
+ctx = rnd(F * K, D).to(dt)
 out = os.path.join(ROOT, "gpurun_out")
 os.makedirs(out, exist_ok=True)
 for m in masks:
@@ -41,6 +43,8 @@ for m in masks:
     d.k, d.ldk, d.vt, d.ldvt, d.bv = k.data_ptr(), k.stride(0), vt.data_ptr(), vt.stride(0), bv.data_ptr()
     d.Nenc, d.ln_g, d.ln_b, d.eps = N, ln_g.data_ptr(), ln_b.data_ptr(), 1e-12
     d.dim, d.heads, d.scale, d.dtype = D, heads, 0.125, L.F16
+    if OUT:
+        d.ctx, d.ldctx = ctx.data_ptr(), ctx.stride(0)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for _ in range(3):
         assert lib.tdc_qformer_xattn(C.byref(d), st) == 0
