@@ -14,7 +14,8 @@ import tdc_video_amd  # noqa: F401,E402
 from tdc_video_amd import lib as L, ops  # noqa: E402
 
 OUT = "--out-only" in sys.argv      # time the ctx form (output projection + residual + LayerNorm alone)
-masks = [int(a) for a in sys.argv[1:] if a != "--out-only"] or [0, 1, 2, 4, 7, 15]
+# a mask may carry defines: "0:XATTN_OUT_OLD" = the ctx form on the 8-wave / 64-row kernel instead of the 4-wave / 32-row one
+masks = [a for a in sys.argv[1:] if a != "--out-only"] or ["0", "1", "2", "4", "7", "15"]
 F, K, N, D, heads, Lt = 439, 144, 156, 768, 12, 12
 S = K + Lt
 dt, dev = torch.float16, "cuda"
@@ -30,9 +31,11 @@ ctx = rnd(F * K, D).to(dt)
 out = os.path.join(ROOT, "gpurun_out")
 os.makedirs(out, exist_ok=True)
 for m in masks:
-    so = os.path.join(out, "xattn_diag_%d.so" % m)
+    m, *defs = m.split(":")
+    m = int(m)
+    so = os.path.join(out, "xattn_diag_%d_%s.so" % (m, "_".join(defs)))
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
-                           "-DXATTN_DIAG=%d" % m, os.path.join(ROOT, "tdc-video_amd", "csrc", "xattn.hip"), "-o", so])
+                           "-DXATTN_DIAG=%d" % m, *["-D" + d for d in defs], os.path.join(ROOT, "tdc-video_amd", "csrc", "xattn.hip"), "-o", so])
     lib = C.CDLL(so)
     lib.tdc_qformer_xattn.restype = C.c_int
     lib.tdc_qformer_xattn.argtypes = [C.POINTER(L.XattnDesc), C.c_void_p]
@@ -54,4 +57,4 @@ for m in masks:
         lib.tdc_qformer_xattn(C.byref(d), st)
     e1.record()
     torch.cuda.synchronize()
-    print("XATTN_DIAG=%2d: %.3f ms per launch" % (m, e0.elapsed_time(e1) / 10), flush=True)
+    print("XATTN_DIAG=%2d %s: %.3f ms per launch" % (m, " ".join(defs), e0.elapsed_time(e1) / 10), flush=True)
