@@ -311,6 +311,11 @@ typedef struct {
      * (row f*K + k), produced by separate launches (q GEMM, tdc_attention); the kernel then computes
      * h[:, :K] = LayerNorm(ctx Wo^T + bo + h[:, :K]) alone: wq / bq / k / vt / bv / Nenc / scale are not read. */
     const void* ctx; int ldctx;
+    /* res16 != 0 (ctx form only): the residual is the 16-bit hidden state - h16 is read as the residual and only h16 is written;
+     * h32 is neither read nor written and may be NULL.  (The arithmetic of the reference's half-precision inference,
+     * tdc/Qformer.py:285-289 on 16-bit tensors; half the bytes of the launch.  tdc_qformer_fwd uses it in its default form
+     * and carries the query rows in 16 bits from here to the LayerNorm behind the layer's query FFN, which writes both copies again.) */
+    int res16;
 } tdc_xattn_desc;
 int tdc_qformer_xattn_supported(int dim, int heads, int K, int Nenc);
 int tdc_qformer_xattn(const tdc_xattn_desc* d, void* stream);

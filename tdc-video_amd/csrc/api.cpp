@@ -170,11 +170,11 @@ QfWs qf_layout(const tdc_qformer_model* m, int F, int K, int Lt, int Nenc) {
     return w;
 }
 
-int ln_map(const float* x, int ldx, void* y16, float* y32, int ld, const float* g, const float* b, float eps, int rows,
-           int cols, int dtype, tdc_rowmap ymap, void* st) {
+int ln_map(const void* x, int ldx, void* y16, float* y32, int ld, const float* g, const float* b, float eps, int rows,
+           int cols, int dtype, tdc_rowmap ymap, void* st, int x_f32 = 1) {
     tdc_ln_desc d;
     memset(&d, 0, sizeof(d));
-    d.x = x; d.ldx = ldx; d.x_f32 = 1; d.y16 = y16; d.ldy16 = ld; d.y32 = y32; d.ldy32 = ld; d.gamma = g; d.beta = b;
+    d.x = x; d.ldx = ldx; d.x_f32 = x_f32; d.y16 = y16; d.ldy16 = ld; d.y32 = y32; d.ldy32 = ld; d.gamma = g; d.beta = b;
     d.eps = eps; d.rows = rows; d.cols = cols; d.dtype = dtype; d.y_map = ymap;
     return tdc_layernorm(&d, st);
 }
@@ -252,6 +252,7 @@ extern "C" int tdc_qformer_fwd(const tdc_qformer_model* m, const void* enc, int 
     const float scale = 1.0f / sqrtf((float)hd);
     for (int l = 0; l < m->n_layers; ++l) {
         const tdc_qformer_layer& L = m->layers_host[l];
+        bool q16 = false;   // this layer's query rows between the cross-attention output and the FFN LayerNorm: 16-bit only (t32 holds 16-bit rows)
         RET_IF(gemm_full(h16, Dp, L.qkv, qkv, L.qkv.n, rows, dt, TDC_ACT_NONE, 0, nullptr, 0, 0, ident, ident, ident,
                          stream));
         tdc_attn_desc a;
@@ -292,6 +293,10 @@ extern "C" int tdc_qformer_fwd(const tdc_qformer_model* m, const void* enc, int 
                 x.h16 = h16; x.h32 = h32; x.ldh = Dp; x.F = F; x.K = K; x.S = S;
                 x.wo = L.cross_out_tiled; x.bo = L.cross_out.b; x.ln_g = L.cross_ln_g; x.ln_b = L.cross_ln_b; x.eps = m->eps;
                 x.dim = D; x.heads = m->heads; x.Nenc = Nenc; x.dtype = dt; x.ctx = ctxq; x.ldctx = Dp;
+                // the residual of this kernel and of the query FFN behind it is the 16-bit hidden state (tdc_xattn_desc.res16):
+                // the fp32 copy of the query rows is not touched until the FFN's LayerNorm rewrites both copies
+                x.res16 = 1; x.h32 = nullptr;
+                q16 = true;
                 RET_IF(tdc_qformer_xattn(&x, stream));
             } else {
                 RET_IF(gemm_full(ctxq, Dp, L.cross_out, t32, Dp, F * K, dt, TDC_ACT_NONE, 1, h32, Dp, 1, ident, ident, qmap,
@@ -301,15 +306,18 @@ extern "C" int tdc_qformer_fwd(const tdc_qformer_model* m, const void* enc, int 
         }
         RET_IF(gemm_full(h16, Dp, L.fq1, mq, L.fq2.k, F * K, dt, TDC_ACT_GELU_ERF, 0, nullptr, 0, 0, qmap, ident, ident,
                          stream));
-        RET_IF(gemm_full(mq, L.fq2.k, L.fq2, t32, Dp, F * K, dt, TDC_ACT_NONE, 1, h32, Dp, 1, ident, ident, qmap,
-                         stream));
+        if (q16)
+            RET_IF(gemm_full(mq, L.fq2.k, L.fq2, t32, Dp, F * K, dt, TDC_ACT_NONE, 0, h16, Dp, 0, ident, ident, qmap, stream));
+        else
+            RET_IF(gemm_full(mq, L.fq2.k, L.fq2, t32, Dp, F * K, dt, TDC_ACT_NONE, 1, h32, Dp, 1, ident, ident, qmap,
+                             stream));
         if (Lt > 0) {
             RET_IF(gemm_full(h16, Dp, L.ft1, mt, L.ft2.k, F * Lt, dt, TDC_ACT_GELU_ERF, 0, nullptr, 0, 0, tmap, ident,
                              ident, stream));
             RET_IF(gemm_full(mt, L.ft2.k, L.ft2, t32b, Dp, F * Lt, dt, TDC_ACT_NONE, 1, h32, Dp, 1, ident, ident, tmap,
                              stream));
         }
-        RET_IF(ln_map(t32, Dp, h16, h32, Dp, L.fq_ln_g, L.fq_ln_b, m->eps, F * K, D, dt, qmap, stream));
+        RET_IF(ln_map(t32, Dp, h16, h32, Dp, L.fq_ln_g, L.fq_ln_b, m->eps, F * K, D, dt, qmap, stream, q16 ? 0 : 1));
         if (Lt > 0)
             RET_IF(ln_map(t32b, Dp, h16, h32, Dp, L.ft_ln_g, L.ft_ln_b, m->eps, F * Lt, D, dt, tmap, stream));
     }

@@ -48,6 +48,7 @@ constexpr int XBUF = XROWS * XD * 2;
 struct XattnArgs {
     const void* h16; float* h32; void* h16_out; int ldh;
     const void* ctx; int ldctx;           // OUT_ONLY form: the attention output of the flat query rows [rows, ldctx]
+    int res16;                            // OUT_ONLY form: residual = the 16-bit rows h16, only h16 is written (no fp32 master)
     int rows, K, S;                       // rows = F*K flat query rows; global row of flat row r: (r / K) * S + r % K
     unsigned invK;                        // floor(2^32 / K)
     const void *wq, *wo; const float *bq, *bo;     // wq / wo: fragment-major copies (tdc_qformer_xattn_tile_weight)
@@ -154,7 +155,8 @@ __device__ __forceinline__ void gemm_64x768(const T* __restrict__ Wt, const char
 
 // NKT: key tiles of 16 (even), Nenc <= 16 NKT.  OUT_ONLY: the block's last third alone - ctx (the attention output, read from
 // global memory) -> output projection + residual + LayerNorm; q projection and attention stay separate launches in front of it.
-template <class T, int NKT, bool OUT_ONLY>
+// RES16 (with OUT_ONLY): the residual is read from the 16-bit rows and only they are written - half the bytes of the launch.
+template <class T, int NKT, bool OUT_ONLY, bool RES16 = false>
 __global__ __launch_bounds__(512, 2) void xattn_kernel(XattnArgs p) {
     typedef typename VecOf<T>::v8 v8;
     typedef typename VecOf<T>::v4 v4;
@@ -406,7 +408,13 @@ __global__ __launch_bounds__(512, 2) void xattn_kernel(XattnArgs p) {
         const f32x4 b4 = *(const f32x4*)(p.bo + n0);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            const f32x4 r4 = *(const f32x4*)(p.h32 + grow[mt] + n0);
+            f32x4 r4;
+            if constexpr (RES16) {
+                const v4 r16 = *(const v4*)((const T*)p.h16 + grow[mt] + n0);
+                r4 = (f32x4){(float)r16[0], (float)r16[1], (float)r16[2], (float)r16[3]};
+            } else {
+                r4 = *(const f32x4*)(p.h32 + grow[mt] + n0);
+            }
             acc[nt][mt] = (acc[nt][mt] + b4) + r4;
             sum[mt] += (acc[nt][mt][0] + acc[nt][mt][1]) + (acc[nt][mt][2] + acc[nt][mt][3]);
         }
@@ -454,6 +462,30 @@ __global__ __launch_bounds__(512, 2) void xattn_kernel(XattnArgs p) {
     // halves of 32 rows (the buffer is free: every wave passed two barriers since its last ctx read), each thread then stores
     // whole 16-byte pieces of consecutive addresses - the fp32 master and, converted on the way out, the 16-bit copy
     T* H16 = (T*)p.h16_out;
+    if constexpr (RES16) {
+        // 16-bit rows only: all 64 rows fit the image, one pass (8-byte pieces in, 16-byte pieces of consecutive addresses out)
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt) {
+            const int n0 = 96 * wave + 16 * nt + 4 * g;
+            const f32x4 g4 = *(const f32x4*)(p.ln_g + n0), b4 = *(const f32x4*)(p.ln_b + n0);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const f32x4 y = (acc[nt][mt] - mean[mt]) * rstd[mt] * g4 + b4;
+                *(v4*)(buf + buf_off(16 * mt + i, n0)) = cvt4<T>(y);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const int idx = tid + j * 512;
+            const int row = idx / 96, ch = idx - row * 96;
+            const int flat = r0 + row;
+            if (flat >= p.rows || (XATTN_DIAG & 8)) continue;
+            const v8 y = *(const v8*)(buf + buf_off(row, ch * 8));
+            *(v8*)(H16 + (long long)grow_of(flat, p.K, p.S, p.invK) * p.ldh + ch * 8) = y;
+        }
+        return;
+    }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         if (half) __syncthreads();                 // the copy-out of the first half is done
@@ -487,22 +519,25 @@ template <class T>
 int launch(const XattnArgs& a, int nkt, hipStream_t st) {
 
     const int grid = ((a.nblocks + 7) / 8) * 8;
-#define XLAUNCH(N, OO)                                                                                                    \
+#define XLAUNCH(N, OO) XLAUNCH_(N, OO, false)
+#define XLAUNCH_(N, OO, R16)                                                                                                  \
     do {                                                                                                                 \
         const size_t lds = XBUF + 2 * 8 * 64 * sizeof(float) + (OO ? 0 : 2 * N * 2048);  /* rows, LayerNorm partials, K / V^T ring */ \
         static bool attr[16];                                                                                            \
         int dev = 0;                                                                                                     \
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return TDC_E_BADARG;                               \
         if (!attr[dev]) {                                                                                                \
-            HIP_CHECK_RET(hipFuncSetAttribute((const void*)xattn_kernel<T, N, OO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            HIP_CHECK_RET(hipFuncSetAttribute((const void*)xattn_kernel<T, N, OO, R16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             attr[dev] = true;                                                                                            \
         }                                                                                                                \
-        hipLaunchKernelGGL((xattn_kernel<T, N, OO>), dim3(grid), dim3(512), lds, st, a);                                 \
+        hipLaunchKernelGGL((xattn_kernel<T, N, OO, R16>), dim3(grid), dim3(512), lds, st, a);                                 \
     } while (0)
-    if (a.ctx) XLAUNCH(10, true);
+    if (a.ctx && a.res16) XLAUNCH_(10, true, true);
+    else if (a.ctx) XLAUNCH(10, true);
     else if (nkt <= 10) XLAUNCH(10, false);
     else XLAUNCH(14, false);
 #undef XLAUNCH
+#undef XLAUNCH_
     return (int)hipGetLastError();
 }
 
@@ -533,8 +568,9 @@ extern "C" int tdc_qformer_xattn_tile_weight(const void* w, int ldw, void* out, 
 }
 
 extern "C" int tdc_qformer_xattn(const tdc_xattn_desc* d, void* stream) {
-    if (!d || !d->h16 || !d->h32 || !d->wo || !d->bo || !d->ln_g || !d->ln_b) return TDC_E_BADARG;
-    const bool out_only = d->ctx != nullptr;
+    const bool out_only = d && d->ctx != nullptr;
+    if (!d || !d->h16 || (!d->h32 && !(out_only && d->res16)) || !d->wo || !d->bo || !d->ln_g || !d->ln_b) return TDC_E_BADARG;
+    if (d->res16 && !out_only) return TDC_E_BADARG;
     if (!out_only && (!d->wq || !d->bq || !d->k || !d->vt)) return TDC_E_BADARG;
     if (!tdc_qformer_xattn_supported(d->dim, d->heads, d->K, out_only ? 8 : d->Nenc) || d->F <= 0 || d->S < d->K) {
         fprintf(stderr, "[tdc_hip] tdc_qformer_xattn: unsupported shape (dim=%d heads=%d K=%d Nenc=%d)\n", d->dim, d->heads, d->K,
@@ -542,7 +578,7 @@ extern "C" int tdc_qformer_xattn(const tdc_xattn_desc* d, void* stream) {
         return TDC_E_BADARG;
     }
     auto al = [](const void* p, int bytes) { return ((uintptr_t)p % bytes) == 0; };
-    if (d->ldh % 8 || d->ldh < XD || !al(d->h16, 16) || !al(d->h32, 16) || !al(d->wo, 16) || !al(d->bo, 16) || !al(d->ln_g, 16) ||
+    if (d->ldh % 8 || d->ldh < XD || !al(d->h16, 16) || (d->h32 && !al(d->h32, 16)) || !al(d->wo, 16) || !al(d->bo, 16) || !al(d->ln_g, 16) ||
         !al(d->ln_b, 16) || (long long)d->F * d->K > 0x7fffffffll || (long long)d->F * d->S * d->ldh > 0x7fffffffll)
         return TDC_E_BADARG;
     if (out_only) {
@@ -553,7 +589,7 @@ extern "C" int tdc_qformer_xattn(const tdc_xattn_desc* d, void* stream) {
     }
     XattnArgs a;
     a.h16 = d->h16; a.h32 = d->h32; a.h16_out = d->h16; a.ldh = d->ldh;
-    a.ctx = d->ctx; a.ldctx = d->ldctx;
+    a.ctx = d->ctx; a.ldctx = d->ldctx; a.res16 = d->res16;
     a.rows = d->F * d->K; a.K = d->K; a.S = d->S;
     a.invK = (unsigned)((1ull << 32) / (unsigned long long)d->K);
     a.wq = d->wq; a.wo = d->wo; a.bq = d->bq; a.bo = d->bo;

@@ -130,7 +130,7 @@ class XattnDesc(C.Structure):
                 ("vt", C.c_void_p), ("ldvt", C.c_longlong), ("bv", C.c_void_p),
                 ("Nenc", C.c_int), ("ln_g", C.c_void_p), ("ln_b", C.c_void_p), ("eps", C.c_float),
                 ("dim", C.c_int), ("heads", C.c_int), ("scale", C.c_float), ("dtype", C.c_int),
-                ("ctx", C.c_void_p), ("ldctx", C.c_int)]
+                ("ctx", C.c_void_p), ("ldctx", C.c_int), ("res16", C.c_int)]
 
 
 # name -> (restype, argtypes); every symbol include/tdc_hip.h declares

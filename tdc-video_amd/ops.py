@@ -475,19 +475,24 @@ def xattn_tile_weight(w):
     return out
 
 
-def qformer_xattn_out(h16, h32, F, K, S, ctx, wo_t, bo, ln_g, ln_b, eps, dim, heads):
+def qformer_xattn_out(h16, h32, F, K, S, ctx, wo_t, bo, ln_g, ln_b, eps, dim, heads, res16=False):
     """The last third of the block alone (tdc_qformer_xattn with ctx): ctx [F*K, ld] = the attention output of the flat query
-    rows -> h16 / h32 query rows = LayerNorm(ctx Wo^T + bo + h)."""
-    for t in (h16, h32, ctx):
+    rows -> h16 / h32 query rows = LayerNorm(ctx Wo^T + bo + h).  res16: the residual is h16 and only h16 is written (h32 may
+    be None)."""
+    for t in (h16, ctx) + (() if (res16 and h32 is None) else (h32,)):
         _chk2d(t, "xattn operand")
-    assert h32.dtype == torch.float32 and h16.dtype == wo_t.dtype == ctx.dtype
-    assert h16.shape[0] >= F * S and h32.shape[0] >= F * S and h16.stride(0) == h32.stride(0) and h16.shape[1] >= dim
+    assert h16.dtype == wo_t.dtype == ctx.dtype and h16.shape[0] >= F * S and h16.shape[1] >= dim
+    if h32 is not None:
+        assert h32.dtype == torch.float32 and h32.shape[0] >= F * S and h16.stride(0) == h32.stride(0)
+    else:
+        assert res16
     assert ctx.shape[0] >= F * K and ctx.shape[1] >= dim and wo_t.is_cuda and wo_t.is_contiguous() and wo_t.numel() == dim * dim
     for v in (bo, ln_g, ln_b):
         assert v.dtype == torch.float32 and v.is_contiguous() and v.numel() >= dim
     d = L.XattnDesc()
-    d.h16, d.h32, d.ldh = h16.data_ptr(), h32.data_ptr(), h16.stride(0)
+    d.h16, d.h32, d.ldh = h16.data_ptr(), (h32.data_ptr() if h32 is not None else None), h16.stride(0)
     d.F, d.K, d.S = F, K, S
+    d.res16 = 1 if res16 else 0
     d.wo, d.bo = wo_t.data_ptr(), bo.data_ptr()
     d.ln_g, d.ln_b, d.eps = ln_g.data_ptr(), ln_b.data_ptr(), eps
     d.dim, d.heads, d.dtype, d.Nenc = dim, heads, _dt(h16), 8

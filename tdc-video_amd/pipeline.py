@@ -478,10 +478,12 @@ class VideoEncoder:
         ctx = torch.zeros(F * S, Dp, device=self.dev, dtype=dt)
         ctx_q = torch.zeros(F * K, Dp, device=self.dev, dtype=dt)
         t32 = torch.empty(F * S, Dp, device=self.dev, dtype=torch.float32)
+        t16 = torch.empty(F * K, Dp, device=self.dev, dtype=dt) if out_fused else None
         scale = 1.0 / math.sqrt(hd)
         qmap = (K, S, 0, 1)
         tmap = (Lt, S, K, 1) if Lt else None
         for Lr in qf.layers:
+            q16 = False          # this layer's query rows between the cross-attention output and the FFN LayerNorm: 16-bit only
             qkv = ops.gemm(h16, Lr.qkv.w, Lr.qkv.b)
             ld = qkv.stride(0)
             ops.attention(qkv[:, 0:Dq], qkv[:, Dq:2 * Dq], qkv[:, 2 * Dq:3 * Dq], ctx, F, heads, hd, S, S, scale,
@@ -503,19 +505,27 @@ class VideoEncoder:
                 ops.attention(cq[:, :Dq], kk, vv, ctx_q, F, heads, hd, K, Nenc, scale, K * cq.stride(0), Nenc * ldk,
                               Nenc * ldk, K * ctx_q.stride(0))
                 if out_fused:
-                    ops.qformer_xattn_out(h16, h32, F, K, S, ctx_q, Lr.cross.out_tiled, Lr.cross.out.b, Lr.cross.ln[0],
-                                          Lr.cross.ln[1], 1e-12, Dq, heads)
+                    # the residual of this kernel and of the query FFN behind it is the 16-bit hidden state (the reference's
+                    # half-precision arithmetic, tdc/Qformer.py:285-289,335-341): the fp32 copy of the query rows is neither
+                    # read nor written until the FFN's LayerNorm rewrites both copies - half the bytes of the kernel
+                    ops.qformer_xattn_out(h16, None, F, K, S, ctx_q, Lr.cross.out_tiled, Lr.cross.out.b, Lr.cross.ln[0],
+                                          Lr.cross.ln[1], 1e-12, Dq, heads, res16=True)
+                    q16 = True
                 else:
                     ops.gemm(ctx_q, Lr.cross.out.w, Lr.cross.out.b, res=h32, r_map=qmap, out=t32, out_f32=True, M=F * K)
                     ops.layernorm(t32, Lr.cross.ln[0], Lr.cross.ln[1], 1e-12, Dq, dt, y16=h16, y32=h32, rows=F * K,
                                   y_map=qmap)
             ops.TAG = None
             m = ops.gemm(h16, Lr.ffn_q.fc1.w, Lr.ffn_q.fc1.b, act=L.ACT_GELU_ERF, M=F * K, a_map=qmap)
-            ops.gemm(m, Lr.ffn_q.fc2.w, Lr.ffn_q.fc2.b, res=h32, r_map=qmap, out=t32, out_f32=True, M=F * K)
+            if q16:
+                ops.gemm(m, Lr.ffn_q.fc2.w, Lr.ffn_q.fc2.b, res=h16, r_map=qmap, out=t16, M=F * K)
+            else:
+                ops.gemm(m, Lr.ffn_q.fc2.w, Lr.ffn_q.fc2.b, res=h32, r_map=qmap, out=t32, out_f32=True, M=F * K)
             if Lt:
                 m2 = ops.gemm(h16, Lr.ffn_t.fc1.w, Lr.ffn_t.fc1.b, act=L.ACT_GELU_ERF, M=F * Lt, a_map=tmap)
                 t32b = ops.gemm(m2, Lr.ffn_t.fc2.w, Lr.ffn_t.fc2.b, res=h32, r_map=tmap, out_f32=True, M=F * Lt)
-            ops.layernorm(t32, Lr.ffn_q.ln[0], Lr.ffn_q.ln[1], 1e-12, Dq, dt, y16=h16, y32=h32, rows=F * K, y_map=qmap)
+            ops.layernorm(t16 if q16 else t32, Lr.ffn_q.ln[0], Lr.ffn_q.ln[1], 1e-12, Dq, dt, y16=h16, y32=h32, rows=F * K,
+                          y_map=qmap)
             if Lt:
                 ops.layernorm(t32b, Lr.ffn_t.ln[0], Lr.ffn_t.ln[1], 1e-12, Dq, dt, y16=h16, y32=h32, rows=F * Lt,
                               y_map=tmap)

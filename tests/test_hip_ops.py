@@ -589,3 +589,9 @@ def test_qformer_xattn_output_projection_only(ops, dtype, F, K, Lt):
     other = torch.ones(F * S, dtype=torch.bool, device=dev)
     other[rows] = False
     assert torch.equal(h16[other], ref16[other]) and torch.equal(h32[other], ref32[other])
+    # res16: the residual is the 16-bit copy and only it is written (tdc_xattn_desc.res16); h32 may be absent
+    h16b = ref16.clone()
+    ops.qformer_xattn_out(h16b, None, F, K, S, ctx, ops.xattn_tile_weight(wo), bo, ln_g, ln_b, 1e-12, D, heads, res16=True)
+    y16 = torch.nn.functional.layer_norm(ctx.float() @ wo.float().t() + bo + ref16[rows].float(), (D,), ln_g, ln_b, 1e-12)
+    assert (h16b[rows].float() - y16).abs().max().item() < (4e-3 if dtype == torch.float16 else 3e-2)
+    assert torch.equal(h16b[other], ref16[other])

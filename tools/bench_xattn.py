@@ -81,7 +81,7 @@ def out_fused(ev=None):
         cq = t("q gemm", lambda: ops.gemm(h16, wq[j], bq, M=F * K, a_map=qmap))
         t("attention", lambda: ops.attention(cq, kv[:, j * 2 * D:j * 2 * D + D], kv[:, j * 2 * D + D:(j + 1) * 2 * D], ctxq, F, heads,
                                              64, K, N, 0.125, K * cq.stride(0), N * ld, N * ld, K * ctxq.stride(0)))
-        t("out kernel", lambda: ops.qformer_xattn_out(h16, h32, F, K, S, ctxq, wo_t[j], bo, ln_g, ln_b, 1e-12, D, heads))
+        t("out kernel", lambda: ops.qformer_xattn_out(h16, None, F, K, S, ctxq, wo_t[j], bo, ln_g, ln_b, 1e-12, D, heads, res16=True))
 
 
 def parts():
