@@ -201,7 +201,8 @@ def main():
                          "3 = as 2 with the MLP hidden written as e4m3 by fc1 itself")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tower-batch", type=int, default=512)
-    ap.add_argument("--two-streams", type=int, default=0, help="run the two towers on two HIP streams")
+    ap.add_argument("--two-streams", type=int, default=-1, help="run the two towers on two HIP streams: 0 / 1, -1 = on at <= 128 "
+                    "frames per rank (small batches leave partly filled last tile rounds, which the other tower's workgroups fill)")
     ap.add_argument("--gemm-shape-times", default="", help="write per-shape GEMM times of the profiled step to this file")
     ap.add_argument("--xattn-mode", type=int, default=1, choices=[0, 1, 2], help="Q-Former cross-attention block: 0 = per-kernel "
                     "sequence (stacked K/V GEMM, q GEMM, tdc_attention, dense GEMM, LayerNorm), 1 = output projection + residual + "
@@ -247,7 +248,8 @@ def main():
     enc = VideoEncoder(sd, cfg, dtype=dtype, device=dev, siglip_heads=16, dino_heads=24, qformer_heads=12,
                        tower_batch=args.tower_batch, fp8_towers=args.fp8_level if args.dtype == "fp8" else 0,
                        tower_dtype=tower_dtype)
-    enc.two_streams = bool(args.two_streams)
+    two_streams = args.two_streams if args.two_streams >= 0 else int((T + world - 1) // world <= 128)
+    enc.two_streams = bool(two_streams)
     enc.xattn_mode = args.xattn_mode
     wav = None
     if args.audio:
@@ -321,7 +323,7 @@ def main():
     ops.PROFILE = None
     this_args = dict(frames=T, K=K, hidden=H, gpus=world, tower_batch=args.tower_batch, dtype=args.dtype, px=args.px,
                      audio=bool(args.audio), fp8_level=args.fp8_level if args.dtype == "fp8" else 0,
-                     two_streams=int(args.two_streams))
+                     two_streams=int(two_streams))
     if args.dump_gemm_shapes and rank == 0:
         with open(args.dump_gemm_shapes + ".args.json", "w") as fh:
             json.dump(this_args, fh)
@@ -415,7 +417,7 @@ def main():
                                "random-init weights, frame cap lifted to T, LLM stubbed%s"
                                % (T, px_s, px_d, H, K, ", + %d s of 16 kHz audio through BEATs (50 audio tokens / frame in "
                                   "the Q-Former KV)" % T if args.audio else ""),
-                   "frames": T, "K": K, "hidden": H, "px": px_s, "parallelism": "frames sharded over %d GPU(s)" % world,
+                   "frames": T, "K": K, "hidden": H, "px": px_s, "parallelism": "frames sharded over %d GPU(s)" % world, "two_streams": bool(two_streams),
                    "emitted_tokens": int(out.shape[0])},
         "rank_ms_per_step": None if rank_ms is None else {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
         "roofline": roofline,

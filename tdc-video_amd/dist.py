@@ -219,6 +219,15 @@ class ShardedVideoEncoder:
             if cfg.get("query_type", "Avg_pool") != "learned":
                 self.comm.exchange([], [])
             return self._gather_tokens(lambda out: None, [len(p) for p in pairs], e.H, e.dtype, px_siglip_local.device)
+        # engine.two_streams (small shards: bench.py switches it on at <= 128 frames per rank): the SigLIP tower runs on a side
+        # stream beside the DINOv2 tower, so the partly filled last tile rounds of one tower's GEMMs are filled by the other's
+        # workgroups (T = 64 on one GPU: +0.6-1.1 %; at 512 frames per launch the tails are too short to matter)
+        side, sig_early = None, None
+        if getattr(e, "two_streams", False) and px_siglip_local.is_cuda:
+            side = torch.cuda.Stream(device=px_siglip_local.device)
+            side.wait_stream(torch.cuda.current_stream(px_siglip_local.device))
+            with torch.cuda.stream(side):
+                sig_early = e.tower("siglip", px_siglip_local)
         dino_all = e.tower("dino", px_dino_local_halo)
         P = dino_all.shape[0] // n_d
         mns = cfg.get("max_num_segments", 24)
@@ -246,7 +255,8 @@ class ShardedVideoEncoder:
             # the host read queues behind the tower (with a host-side transport - gloo - the device is synchronised anyway)
             ev = e.mark() if (hasattr(e, "mark") and sims_local.is_cuda and not getattr(self.comm, "_host_side_now", lambda: True)()) \
                 else None
-            sig = e.tower("siglip", px_siglip_local)
+            if side is None:
+                sig = e.tower("siglip", px_siglip_local)
             counts = [(h - l) - (0 if r < world - 1 else 1) for r, (l, h) in enumerate(ranges)]
             if ev is not None:
                 with e.after(ev):
@@ -258,7 +268,11 @@ class ShardedVideoEncoder:
             seg_idx = seg.select_segments(sims, mns)
         dino = dino_all[: Tl * P]
         # 2. local towers + connector (+ audio rows of the local frames)
-        if sig is None:
+        if side is not None:
+            torch.cuda.current_stream(px_siglip_local.device).wait_stream(side)
+            sig = sig_early
+            sig.record_stream(torch.cuda.current_stream(px_siglip_local.device))
+        elif sig is None:
             sig = e.tower("siglip", px_siglip_local)
         X, sizes = e.connector(sig, dino, Tl, [tuple(image_size)] * Tl)
         N = X.shape[0] // Tl

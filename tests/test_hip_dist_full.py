@@ -68,7 +68,7 @@ def _serial(enc, wav, T):
                             audio={"audio_wav": wav} if wav is not None else None)
 
 
-def _worker(rank, world, port, audio, q, backend="gloo"):
+def _worker(rank, world, port, audio, q, backend="gloo", two_streams=False):
     """backend "gloo": every rank on cuda:0 (a one-GPU box); "nccl": rank r on cuda:r - RCCL over xGMI, the product transport"""
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -83,9 +83,11 @@ def _worker(rank, world, port, audio, q, backend="gloo"):
     try:
         T = PER_RANK * world
         enc, wav = _engine(T, audio, dev_index)
+        enc.two_streams = two_streams          # SigLIP on a side stream beside DINOv2 (dist.py: small shards)
         out = _sharded(enc, wav, T, rank, world)
         ok, shape = None, tuple(out.shape)
         if rank == 0:
+            enc.two_streams = False
             want = _serial(enc, wav, T)
             ok = bool(want.shape == out.shape and torch.equal(want, out))
         # every rank holds the same gathered stream: compare checksums across ranks in the parent
@@ -109,9 +111,10 @@ def _n_gpus():
         return 0
 
 
-@pytest.mark.parametrize("world,audio,backend", [(2, False, "gloo"), (2, True, "gloo"), (4, False, "gloo"),
-                                                 (2, False, "nccl"), (2, True, "nccl"), (4, False, "nccl"), (8, False, "nccl")])
-def test_fullsize_sharded_processes_equal_serial(world, audio, backend):
+@pytest.mark.parametrize("world,audio,backend,two_streams",
+                         [(2, False, "gloo", False), (2, True, "gloo", False), (4, False, "gloo", False), (2, False, "gloo", True),
+                          (2, False, "nccl", False), (2, True, "nccl", False), (4, False, "nccl", True), (8, False, "nccl", True)])
+def test_fullsize_sharded_processes_equal_serial(world, audio, backend, two_streams):
     """backend nccl: one GPU per rank over RCCL - runs wherever the box has >= world GPUs (skipped on a one-GPU box, picked up
     automatically on an 8-GPU node): the boundary-feature point-to-point exchange, the similarity all-gather, the query
     hand-off and the buffered token all_gather_into_tensor on the transport the product uses."""
@@ -120,7 +123,7 @@ def test_fullsize_sharded_processes_equal_serial(world, audio, backend):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, audio, q, backend)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, audio, q, backend, two_streams)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in range(world)]
