@@ -1,6 +1,6 @@
 """bench.py - frames/s of TDC-Video's video-encoding hot path (encode + compress) on N MI355X GPUs of one node.
 
-  python bench.py --gpus 1 --steps K --warmup W                      (N=1)
+  python bench.py --gpus N --steps K --warmup W                      (N=1; N>1: starts its own N ranks, one per GPU)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W   (N>1, one rank/GPU)
 
 A "step" = one pass of the hot path (S0-S10 of SURVEY.md 3.2: DINOv2-g + SigLIP-so400m towers, adjacent-frame
@@ -182,6 +182,46 @@ def cpu_baseline(sd_cpu, cfg, H, K, px_s, px_d):
                        % (cores, n_v, t_v, runs[0], runs[2], t_c))
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher (the reference's eval drivers start one worker per GPU the same way,
+    /root/reference/eval/eval_mlvu.py:129-157): N fresh child processes of this script, one per GPU, with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set; rank 0's stdout (the JSON line) is this process's stdout,
+    the other ranks' stdout goes to stderr.  Returns the worst child return code; when one child fails the others are
+    terminated (a failed rank is never restarted in place)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    worst = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0 and worst == 0:
+                worst = rc
+                sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, rc))
+                for o in live:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    for pr in procs:
+        try:
+            pr.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,6 +235,10 @@ def main():
                          "tokens pass the north_star's 1e-3 against the fp32 oracle at full depth (tests/test_hip_configs.py); "
                          "fp8 (BASELINE config 5): e4m3 operands for the towers' LayerNorm-fed GEMMs (qkv, fc1) through "
                          "v_mfma_f32_16x16x128_f8f6f4, bf16 everywhere else")
+    ap.add_argument("--res", default="fp16", choices=["fp16", "fp32"],
+                    help="the towers' residual stream in HBM: fp16 (default; the reference's own arithmetic - its HF towers run "
+                         "under torch_dtype=float16 - 4 B per element and residual add, sums formed in fp32 and rounded once) or fp32 "
+                         "(8 B per element: rounds 1-3)")
     ap.add_argument("--px", type=int, default=384, help="SigLIP input size (DINO uses px-6: 378); 336 -> 336/336")
     ap.add_argument("--fp8-level", type=int, default=1, choices=[1, 2, 3],
                     help="--dtype fp8: 1 = qkv / fc1 (quantised by the LayerNorm kernel), 2 = also out-proj / fc2, "
@@ -215,10 +259,16 @@ def main():
     ap.add_argument("--dump-gemm-shapes", default=None, help="write the GEMM launches of one step (for tools/gemm_pmc)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing above has touched the GPU (no torch.cuda call), and
+        # nothing below this branch runs in this process.
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (run `python bench.py --gpus N` by itself, or under "
+                 "torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
     # test hooks (never set by the driver): TDC_BENCH_ONE_GPU=1 maps every rank onto GPU 0 and TDC_DIST_BACKEND=gloo
     # swaps the transport, so the N>1 code path can be exercised on a 1-GPU box
     if os.environ.get("TDC_BENCH_ONE_GPU"):
@@ -247,7 +297,8 @@ def main():
     sd = random_state_dict(H, K, dev, gen, siglip_px=px_s)
     enc = VideoEncoder(sd, cfg, dtype=dtype, device=dev, siglip_heads=16, dino_heads=24, qformer_heads=12,
                        tower_batch=args.tower_batch, fp8_towers=args.fp8_level if args.dtype == "fp8" else 0,
-                       tower_dtype=tower_dtype)
+                       tower_dtype=tower_dtype,
+                       tower_res_dtype=torch.float16 if (args.res == "fp16" and args.dtype != "fp8") else None)
     two_streams = args.two_streams if args.two_streams >= 0 else int((T + world - 1) // world <= 128)
     enc.two_streams = bool(two_streams)
     enc.xattn_mode = args.xattn_mode
@@ -315,47 +366,54 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     fps = T * args.steps / dt
 
-    # ---- roofline of the dominant kernel (tdc_gemm MFMA kernel): one extra profiled pass, events on the launch stream
-    ops.PROFILE = {"gemm": [], "attn": [], "gemm_shapes": [], "xattn": [], "ln": [], "tag:xattn_block": []}
+    # ---- roofline of the dominant kernel (tdc_gemm MFMA kernel): one extra pass under the library's launch profiler
+    # (tdc_profile_*: hipEvents recorded inside libtdc_hip.so around every GEMM / attention / LayerNorm / fused cross-attention
+    # launch, on the stream the kernel is launched on) - the SAME host path as the timed steps: the C++ composites
+    # tdc_vit_fwd / tdc_connector_fwd / tdc_qformer_fwd, not a per-kernel Python replay of them
+    ops.profile_start()
     step()
     torch.cuda.synchronize()
-    prof = ops.PROFILE
-    ops.PROFILE = None
+    recs = ops.profile_stop()
     this_args = dict(frames=T, K=K, hidden=H, gpus=world, tower_batch=args.tower_batch, dtype=args.dtype, px=args.px,
                      audio=bool(args.audio), fp8_level=args.fp8_level if args.dtype == "fp8" else 0,
-                     two_streams=int(two_streams))
+                     two_streams=int(two_streams), res=args.res)
+    gemms = [r for r in recs if r["kind"] == "gemm"]
+    shape_of = lambda r: (r["M"], r["N"], r["K"], r["act"], int(r["res"] != 0), r["out_f32"])      # noqa: E731
     if args.dump_gemm_shapes and rank == 0:
         with open(args.dump_gemm_shapes + ".args.json", "w") as fh:
             json.dump(this_args, fh)
         import collections
-        cnt = collections.Counter(prof["gemm_shapes"])
+        cnt = collections.Counter((r["M"], r["N"], r["K"], r["act"], r["res"], r["out_f32"]) for r in gemms)
         with open(args.dump_gemm_shapes, "w") as fh:
+            # res: 0 = none, 1 = fp32, 2 = 16-bit (the replay tool allocates the residual / output accordingly)
             for (M_, N_, K_, act_, res_, of_), c in sorted(cnt.items(), key=lambda kv: -kv[0][0] * kv[0][1] * kv[0][2] * kv[1]):
                 fh.write("%d %d %d %d %d %d %d\n" % (M_, N_, K_, act_, res_, of_, c))
-    if args.gemm_shape_times and rank == 0 and len(prof["gemm_shapes"]) == len(prof["gemm"]):
+    if args.gemm_shape_times and rank == 0:
         import collections
         agg = collections.OrderedDict()
-        for shp, (e0, e1, w) in zip(prof["gemm_shapes"], prof["gemm"]):
-            a = agg.setdefault(shp, [0, 0.0, 0.0])
-            a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += w
+        for r in gemms:
+            a = agg.setdefault((r["M"], r["N"], r["K"], r["act"], r["res"], r["out_f32"]), [0, 0.0, 0.0])
+            a[0] += 1; a[1] += r["ms"]; a[2] += r["flops"]
         with open(args.gemm_shape_times, "w") as fh:
-            fh.write("# M N K act res out_f32 | launches, total ms of the profiled step, TFLOP/s (real dims)\n")
+            fh.write("# M N K act res(0 none, 1 fp32, 2 16-bit) out_f32 | launches, total ms of the profiled step, TFLOP/s (real dims)\n")
             for shp, (c, ms_, w) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 fh.write("%7d %5d %5d %d %d %d | %4d %9.3f ms %8.1f TF/s\n" % (shp + (c, ms_, w / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0)))
-    g_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof["gemm"])
-    g_fl = sum(w for _, _, w in prof["gemm"])
-    a_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof["attn"])
-    a_fl = sum(w for _, _, w in prof["attn"])
+    g_ms = sum(r["ms"] for r in gemms)
+    g_fl = sum(r["flops"] for r in gemms)
+    attns = [r for r in recs if r["kind"] == "attn"]
+    a_ms = sum(r["ms"] for r in attns)
+    a_fl = sum(r["flops"] for r in attns)
+    ln_ms = sum(r["ms"] for r in recs if r["kind"] == "ln")
     achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
     # the north_star's kernel scope: the Q-Former cross-attention BLOCK = K/V projections of the encoder tokens
-    # + q projection + QK^T / softmax / PV + output projection + residual + LayerNorm, all six cross layers; every launch of it is
-    # tagged in pipeline.qformer and timed with events on the launch stream; algorithmic FLOPs = the GEMM / attention counts
-    xb = prof["tag:xattn_block"]
-    xb_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in xb)
-    xb_fl = sum(w for _, _, w, _ in xb)
+    # + q projection + QK^T / softmax / PV + output projection + residual + LayerNorm, all six cross layers; tdc_qformer_fwd tags
+    # every launch of it (TDC_PROF_TAG_XATTN_BLOCK); algorithmic FLOPs = the GEMM / attention counts
+    xb = [r for r in recs if r["tag"] == 1]
+    xb_ms = sum(r["ms"] for r in xb)
+    xb_fl = sum(r["flops"] for r in xb)
     xb_kinds = {}
-    for e0, e1, _, kind in xb:
-        xb_kinds[kind] = round(xb_kinds.get(kind, 0.0) + e0.elapsed_time(e1), 3)
+    for r in xb:
+        xb_kinds[r["kind"]] = round(xb_kinds.get(r["kind"], 0.0) + r["ms"], 3)
     xb_tf = xb_fl / (xb_ms * 1e-3) / 1e12 if xb_ms > 0 else None
     # HBM-side traffic per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction).  They cannot be
     # collected inside this process (rocprofv3 --pmc segfaults in a torch process on this image), so they come from a
@@ -379,16 +437,19 @@ def main():
     peak = 2.0 * MFMA_PEAK_TFLOPS if (args.dtype == "fp8" and args.fp8_level >= 2) else MFMA_PEAK_TFLOPS
     a_tf = a_fl / (a_ms * 1e-3) / 1e12 if a_ms > 0 else None
     # whole step: every algorithmic FLOP of the pass (GEMMs + attention; the rest is byte work) over the TIMED step time
-    x_fl = sum(w for _, _, w in prof["xattn"])       # the fused cross-attention kernel's own GEMM / attention FLOPs
+    x_fl = sum(r["flops"] for r in recs if r["kind"] == "xattn")       # the fused cross-attention kernel's own GEMM / attention FLOPs
     step_tf = (g_fl + a_fl + x_fl) / (ms_per_step * 1e-3) / 1e12 * (world if world > 1 else 1)
     roofline = dict(bound="mfma", achieved=round(achieved, 1), peak=peak, unit="TFLOP/s",
                     frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_source,
                     kernel="gemm256p_kernel / gemm256_kernel / gemm_kernel (tdc_gemm)",
-                    launches=len(prof["gemm"]), avg_launch_us=round(g_ms * 1e3 / max(1, len(prof["gemm"])), 2),
+                    launches=len(gemms), avg_launch_us=round(g_ms * 1e3 / max(1, len(gemms)), 2),
+                    host_path="C++ composites (tdc_vit_fwd / tdc_connector_fwd / tdc_qformer_fwd): the path of the timed steps; "
+                              "events recorded inside libtdc_hip.so (tdc_profile_*)",
+                    layernorm_ms_per_step=round(ln_ms, 2),
                     gemm_ms_per_step=round(g_ms, 2), gemm_tflop_per_step=round(g_fl / 1e12, 2),
                     attention=dict(ms_per_step=round(a_ms, 2), tflops=round(a_tf, 1) if a_tf else None,
                                    frac=round(a_tf / MFMA_PEAK_TFLOPS, 4) if a_tf else None,
-                                   launches=len(prof["attn"])),
+                                   launches=len(attns)),
                     whole_step=dict(tflops=round(step_tf, 1), frac=round(step_tf / (peak * world), 4),
                                     note="(GEMM + attention + fused cross-attention FLOPs of this rank x ranks) / timed step; peak x ranks"),
                     xattn_block=dict(ms_per_step=round(xb_ms, 3), tflop_per_step=round(xb_fl / 1e12, 3),
@@ -410,14 +471,16 @@ def main():
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": ("fp8 (e4m3 operands: %s) + bf16" % ("all four tower GEMMs" if args.fp8_level >= 2 else "qkv / fc1")) if args.dtype == "fp8"
-                 else "bf16 (ViT towers) + fp16 (connector, Q-Former)" if args.dtype == "mixed" else args.dtype,
+                 else ("bf16 (ViT tower operands, %s residual stream) + fp16 (connector, Q-Former)" % args.res) if args.dtype == "mixed"
+                 else "%s (%s tower residual stream)" % (args.dtype, args.res),
         "data": "synthetic",
         "config": {"workload": "one %d-frame video, SigLIP-so400m/14@%d + DINOv2-giant/14@%d towers (729 patches -> 576 "
                                "tokens), SVA 576->144, mm_projector -> H=%d, Q-Former TDC K=%d (N=156, 12 prompt ids), "
                                "random-init weights, frame cap lifted to T, LLM stubbed%s"
                                % (T, px_s, px_d, H, K, ", + %d s of 16 kHz audio through BEATs (50 audio tokens / frame in "
                                   "the Q-Former KV)" % T if args.audio else ""),
-                   "frames": T, "K": K, "hidden": H, "px": px_s, "parallelism": "frames sharded over %d GPU(s)" % world, "two_streams": bool(two_streams),
+                   "frames": T, "K": K, "hidden": H, "px": px_s, "tower_residual": args.res if args.dtype != "fp8" else "fp32",
+                   "parallelism": "frames sharded over %d GPU(s)" % world, "two_streams": bool(two_streams),
                    "emitted_tokens": int(out.shape[0])},
         "rank_ms_per_step": None if rank_ms is None else {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
         "roofline": roofline,

@@ -77,6 +77,11 @@ typedef struct {
      * N % 8 == 4 (unspecified values there) instead of falling back to 8-byte stores.  Used by the transposed value
      * projection of the Q-Former (N = frames x tokens). */
     int c_pad8;
+    /* c16_dtype_p1 != 0: the 16-bit type of C and of a 16-bit res is (c16_dtype_p1 - 1) instead of `dtype` (0 = `dtype`, so a
+     * zero-initialised descriptor keeps the operand type).  For the residual-stream GEMMs of a tower whose operands are bf16
+     * and whose residual stream is kept in fp16 (tdc_vit_model.res_dtype_p1): C = fp16(acc + bias + float(res)), one rounding.
+     * Needs 16-bit C (out_f32 == 0), act == NONE, no LayerNorm-fusion / fp8 operand. */
+    int c16_dtype_p1;
 } tdc_gemm_desc;
 int tdc_gemm(const tdc_gemm_desc* d, void* stream);
 /* Diagnostics only (tools/, never the product path): 1 = skip the C-tile epilogue (nothing is written), 2 = un-staged
@@ -111,6 +116,9 @@ typedef struct {
      * the ln_stats operand of the fp8-operand tdc_gemm that consumes y8 (y8_wscale = that GEMM's per-tensor weight scale;
      * the first entry - an upper bound of the 2-norm of the QUANTISED row - only matters to tdc_gemm_desc.out_fp8). */
     void* y8; int ldy8; float* y8_stats; float y8_wscale;
+    /* x_dtype_p1 != 0 (with x_f32 == 0): the 16-bit type of x is (x_dtype_p1 - 1) instead of `dtype` (0 = `dtype`): an fp16
+     * residual stream normalised into bf16 GEMM operands.  Needs y32 == NULL, y8 == NULL, add == NULL, cols % 8 == 0. */
+    int x_dtype_p1;
 } tdc_ln_desc;
 int tdc_layernorm(const tdc_ln_desc* d, void* stream);
 
@@ -148,6 +156,8 @@ int tdc_im2col(const void* px, int px_f32, void* patches, int ldp, int B, int H,
                void* stream);
 /* x32 [B, S, ld] rows `row` of every batch := vec[ld] (cls token + pos[0]) */
 int tdc_set_rows(float* x32, int ld, int B, int S, int row, const float* vec, void* stream);
+/* the same into a 16-bit matrix x16 [B*S, ld] of type `dtype` (vec stays fp32): the cls row of a 16-bit residual stream */
+int tdc_set_rows16(void* x16, int ld, int B, int S, int row, const float* vec, int dtype, void* stream);
 /* separable 2-tap resample of a token grid: x (fp32 or 16-bit `dtype`) [B, tok_off + n_in*n_in, ldx] -> y 16-bit
  * (`out_dtype`: may differ from `dtype` - bf16 towers feeding an fp16 connector) [B, n_out*n_out, ldy]; idx0/idx1/frac are
  * device arrays [n_out] (bilinear, align_corners=False; built by host).
@@ -206,7 +216,7 @@ int tdc_qformer_embed(const tdc_qembed_desc* d, void* stream);
  * optional final LN - with `fused` the two LayerNorms of a block are not kernels: the residual-stream GEMM before them
  * emits the 16-bit row copy + per-slot statistics and the GEMM after them folds (mean, rstd) into its epilogue -, bilinear resample of the token grid (cls dropped).  Weights are the prepared (padded, fused,
  * LayerScale-folded) tensors of tdc-video_amd/weights.py; all pointers are device pointers except `layers`
- * (host array).  The residual stream is fp32.  Nothing is allocated: the caller passes a workspace of at least
+ * (host array).  The residual stream is fp32 or 16-bit (res_dtype_p1).  Nothing is allocated: the caller passes a workspace of at least
  * tdc_vit_workspace_bytes() bytes (256-byte aligned). */
 typedef struct { const void* w; const float* b; int n, k; } tdc_lin;      /* w [n, k] 16-bit (padded), b [n] or NULL */
 typedef struct {
@@ -238,12 +248,19 @@ typedef struct {
                                         (attention output, MLP hidden) quantised per row by tdc_quantize_rows_fp8; 3: as 2, but
                                         fc1 writes the MLP hidden as e4m3 itself (tdc_gemm_desc.out_fp8; needs fc1's output
                                         width == fc2.k) */
-    int out_dtype;                   /* TDC_F16 / TDC_BF16: 16-bit type of tdc_vit_fwd's `out` rows.  Set it explicitly; it may
-                                        differ from `dtype` (the towers - 98 % of the FLOPs - in bf16, the connector and the
-                                        Q-Former behind them in fp16: compressed tokens within 1e-3 of the fp32 oracle) */
+    int out_dtype_p1;                /* 16-bit type of tdc_vit_fwd's `out` rows, PLUS ONE: 0 = the same as `dtype` (so a
+                                        zero-initialised struct behaves as before the field existed), TDC_F16 + 1 / TDC_BF16 + 1
+                                        = that type (the towers - 98 % of the FLOPs - in bf16, the connector and the Q-Former
+                                        behind them in fp16: compressed tokens within 1e-3 of the fp32 oracle) */
+    int res_dtype_p1;                /* type of the residual stream in HBM: 0 = fp32 (read-modify-write in the out-projection /
+                                        fc2 epilogues, 8 B per element), TDC_F16 + 1 / TDC_BF16 + 1 = that 16-bit type (4 B per
+                                        element and half the LayerNorm input bytes; fp16 is the reference's own arithmetic: its
+                                        HF towers run under torch_dtype=float16, tdc/builder.py:69, residual adds included).
+                                        Sums are formed in fp32 and rounded once: x <- T16(acc + bias + float(x)).  Excludes
+                                        `fused` and `fp8`. */
 } tdc_vit_model;
 size_t tdc_vit_workspace_bytes(const tdc_vit_model* m, int B, int H, int W);
-/* px [B,3,H,W] (px_f32 as in tdc_im2col: 0 = `dtype`, 1 = fp32, 2 = the other 16-bit type) -> out [B*out_grid*out_grid, ldo] 16-bit `out_dtype`; idx0/idx1/frac: bilinear tables
+/* px [B,3,H,W] (px_f32 as in tdc_im2col: 0 = `dtype`, 1 = fp32, 2 = the other 16-bit type) -> out [B*out_grid*out_grid, ldo] 16-bit (`out_dtype_p1`); idx0/idx1/frac: bilinear tables
  * [out_grid] for the (H/patch)-wide grid (device).  H == W required (the reference pads frames to squares). */
 int tdc_vit_fwd(const tdc_vit_model* m, const void* px, int px_f32, int B, int H, int W, int out_grid,
                 const int* idx0, const int* idx1, const float* frac, void* out, int ldo, void* workspace,
@@ -293,7 +310,8 @@ size_t tdc_qformer_workspace_bytes(const tdc_qformer_model* m, int F, int K, int
  * h16 / h32: the 16-bit copy and the fp32 master of the hidden stream [F*S, ldh] (query rows of frame f = rows f*S + [0, K));
  * both are updated in place.  k [F*Nenc, ldk]: this layer's key rows (enc Wk^T + bk; pass the column-offset pointer);
  * vt [dim, ldvt]: this layer's values TRANSPOSED, vt[c][f*Nenc + key] = (enc Wv^T)[f*Nenc + key][c] WITHOUT the bias -
- * i.e. tdc_gemm with A = Wv, W = enc -; bv [dim] fp32 or NULL.  wq / wo: the two [dim, dim] weights in the kernel's
+ * i.e. tdc_gemm with A = Wv, W = enc -, ldvt >= round_up(F*Nenc, 8) (with Nenc % 8 == 4 the last, half-valid key group of a
+ * frame is read as one 16-byte piece: the last frame's read runs 4 columns past F*Nenc, values unused); bv [dim] fp32 or NULL.  wq / wo: the two [dim, dim] weights in the kernel's
  * FRAGMENT-MAJOR layout, dim*dim 16-bit values each, made once per weight by tdc_qformer_xattn_tile_weight from the
  * nn.Linear layout [dim, ldw] (a wave's MFMA operand is then 1 KiB of consecutive bytes instead of 16 rows x 64 B).
  * Supported: dim == 768, head dim 64, K % 16 == 0, Nenc % 4 == 0, 8 <= Nenc <= 224 (tdc_qformer_xattn_supported); the
@@ -384,6 +402,33 @@ int tdc_fbank(const void* wav, int wav_f32, long long n_samples, long long wav_b
  * [heads]; gate [rows, ldg] fp32 = ga * (gb * grep_a[h] - 1) + 2.  Consumed by tdc_attention's `gate`. */
 int tdc_relpos_gate(const void* q, int ldq, int rows, int heads, int head_dim, const float* w2, const float* b2,
                     const float* grep_a, float* gate, int ldg, int dtype, void* stream);
+
+/* ---- launch profiler -------------------------------------------------------------------------------------------------
+ * Between tdc_profile_start and tdc_profile_stop every tdc_gemm / tdc_attention / tdc_layernorm / tdc_qformer_xattn launch -
+ * called directly or from inside a composite (tdc_vit_fwd, tdc_connector_fwd, tdc_qformer_fwd) - is bracketed by two
+ * hipEvents on its launch stream and leaves one record.  tdc_profile_stop waits for the recorded events, fills `recs` (at
+ * most `cap`) and returns the number of launches seen (negative TDC_E* on error).  tdc_profile_tag sets the tag copied into
+ * the records that follow (returns the previous one); tdc_qformer_fwd tags the launches of the cross-attention block
+ *  with TDC_PROF_TAG_XATTN_BLOCK by itself.  One profile at a time per process; off by default (one global word
+ * is tested per launch).  Measurement infrastructure of bench.py: the profiled step runs the same host path as the timed one. */
+#define TDC_PROF_GEMM 1
+#define TDC_PROF_ATTN 2
+#define TDC_PROF_LN 3
+#define TDC_PROF_XATTN 4
+#define TDC_PROF_TAG_XATTN_BLOCK 1
+typedef struct {
+    int kind, tag;
+    float ms;                       /* elapsed between the two events */
+    int M, N, K, act, res, out_f32; /* GEMM: the launch's shape / epilogue (N, K as passed: padded); ATTN: M = batch * heads,
+                                       N = sq, K = sk, act = head_dim; LN: M = rows, N = cols; XATTN: M = F * K rows, N = Nenc,
+                                       act = 1 for the output-projection form */
+    const void* W;                  /* GEMM: the weight pointer (callers map it to the un-padded dims) */
+    double flops;                   /* algorithmic FLOPs of the launch from the dims as passed (GEMM 2 M N K, attention
+                                       4 b h sq sk d, XATTN its GEMM + attention products); 0 for LN */
+} tdc_prof_rec;
+int tdc_profile_start(int max_records);
+int tdc_profile_stop(tdc_prof_rec* recs, int cap);
+int tdc_profile_tag(int tag);
 
 /* library / device info */
 const char* tdc_version(void);

@@ -152,7 +152,7 @@ QfWs qf_layout(const tdc_qformer_model* m, int F, int K, int Lt, int Nenc) {
     w.h16 = off;  off += al256(rows * Dp * 2);
     w.vt = 0; w.ldvt = 0;
     if (qf_fused(m, K, Nenc)) {     // keys [F*Nenc, n_cross*dim] and transposed values [n_cross*dim, ldvt]
-        w.ldvt = ((size_t)F * Nenc + 63) / 64 * 64;
+        w.ldvt = ((size_t)F * Nenc + 4 + 63) / 64 * 64;     // + 4: the half-valid last key group of a frame is read as 8 columns
         w.kv = off;   off += al256((size_t)F * Nenc * m->cross_k.n * 2);
         w.vt = off;   off += al256((size_t)m->cross_v.n * w.ldvt * 2);
     } else {
@@ -235,6 +235,7 @@ extern "C" int tdc_qformer_fwd(const tdc_qformer_model* m, const void* enc, int 
     }
     const int mode = qf_mode(m, K, Nenc);
     const bool fused = mode == 2;
+    tdc_profile_tag(TDC_PROF_TAG_XATTN_BLOCK);          // the cross-attention block's launches, for tdc_profile_*
     if (fused) {
         // keys of all cross layers: one GEMM; values of all cross layers TRANSPOSED: one GEMM with the operands swapped
         // (A = Wv [n_cross*dim, H], "weight" = enc [F*Nenc, H]) - vt[c][f*Nenc + key], the A operand of the PV product
@@ -249,6 +250,7 @@ extern "C" int tdc_qformer_fwd(const tdc_qformer_model* m, const void* enc, int 
         RET_IF(gemm_full(enc, ldenc, m->cross_kv, kv, m->cross_kv.n, F * Nenc, dt, TDC_ACT_NONE, 0, nullptr, 0, 0, ident,
                          ident, ident, stream));
     }
+    tdc_profile_tag(0);
     const float scale = 1.0f / sqrtf((float)hd);
     for (int l = 0; l < m->n_layers; ++l) {
         const tdc_qformer_layer& L = m->layers_host[l];
@@ -265,6 +267,7 @@ extern "C" int tdc_qformer_fwd(const tdc_qformer_model* m, const void* enc, int 
         RET_IF(gemm_full(ctx, Dp, L.attn_out, t32, Dp, rows, dt, TDC_ACT_NONE, 1, h32, Dp, 1, ident, ident, ident,
                          stream));
         RET_IF(ln_map(t32, Dp, h16, h32, Dp, L.attn_ln_g, L.attn_ln_b, m->eps, rows, D, dt, ident, stream));
+        if (L.has_cross) tdc_profile_tag(TDC_PROF_TAG_XATTN_BLOCK);
         if (L.has_cross && fused) {
             tdc_xattn_desc x;
             memset(&x, 0, sizeof(x));
@@ -304,6 +307,7 @@ extern "C" int tdc_qformer_fwd(const tdc_qformer_model* m, const void* enc, int 
                 RET_IF(ln_map(t32, Dp, h16, h32, Dp, L.cross_ln_g, L.cross_ln_b, m->eps, F * K, D, dt, qmap, stream));
             }
         }
+        tdc_profile_tag(0);
         RET_IF(gemm_full(h16, Dp, L.fq1, mq, L.fq2.k, F * K, dt, TDC_ACT_GELU_ERF, 0, nullptr, 0, 0, qmap, ident, ident,
                          stream));
         if (q16)
@@ -349,12 +353,12 @@ extern "C" int tdc_vit_fwd(const tdc_vit_model* m, const void* px, int px_f32, i
     const tdc_rowmap ident = {0, 0, 0, 0};
     // patch embedding: im2col + GEMM, position rows added in the epilogue, output rows skip the cls slot
     RET_IF(tdc_im2col(px, px_f32, patches, m->patch_lin.k, B, H, W, m->patch, dt, stream));
-    {
+    if (!m->res_dtype_p1) {
         tdc_rowmap cmap = {P, S, m->has_cls, 1}, rmap = {P, 0, m->has_cls, 1};
         RET_IF(gemm(patches, m->patch_lin.k, m->patch_lin, x32, Dp, B * P, dt, TDC_ACT_NONE, 1, m->pos, m->ldpos, 1,
                     cmap, rmap, stream));
+        if (m->has_cls) RET_IF(tdc_set_rows(x32, Dp, B, S, 0, m->cls_row, stream));
     }
-    if (m->has_cls) RET_IF(tdc_set_rows(x32, Dp, B, S, 0, m->cls_row, stream));
     // attention output pad columns must be zero (K padding of the out-projection)
     if (Dp != D) {
         // one-time clear through the LayerNorm kernel is not possible; the pad columns of `attn` are zeroed by writing
@@ -363,6 +367,60 @@ extern "C" int tdc_vit_fwd(const tdc_vit_model* m, const void* px, int px_f32, i
         if (e != hipSuccess) return (int)e;
     }
     const float scale = 1.0f / sqrtf((float)m->head_dim);
+    const int out_dt = m->out_dtype_p1 ? m->out_dtype_p1 - 1 : dt;
+    if (m->res_dtype_p1) {
+        // 16-bit residual stream (tdc_vit_model.res_dtype_p1): x lives in the x32 region as rows of type `rt`; the out-projection
+        // and fc2 GEMMs read-modify-write it in 16 bits (one rounding of acc + bias + float(x)), the LayerNorms read 16-bit rows
+        const int rt = m->res_dtype_p1 - 1;
+        if ((rt != TDC_F16 && rt != TDC_BF16) || m->fused || m->fp8 || (out_dt != TDC_F16 && out_dt != TDC_BF16)) return TDC_E_BADARG;
+        void* x16 = x32;
+        auto gemm_c16 = [&](const void* A, int lda, const tdc_lin& L, int M, const void* res, int ldres, int res_f32,
+                            tdc_rowmap cmap, tdc_rowmap rmap) {
+            tdc_gemm_desc d;
+            memset(&d, 0, sizeof(d));
+            d.A = A; d.lda = lda; d.W = L.w; d.ldw = L.k; d.C = x16; d.ldc = Dp; d.bias = L.b; d.res = res; d.ldres = ldres;
+            d.M = M; d.N = L.n; d.K = L.k; d.dtype = dt; d.res_f32 = res_f32; d.c_map = cmap; d.r_map = rmap;
+            d.c16_dtype_p1 = rt + 1;
+            return tdc_gemm(&d, stream);
+        };
+        auto ln16 = [&](const float* g, const float* b) {
+            tdc_ln_desc d;
+            memset(&d, 0, sizeof(d));
+            d.x = x16; d.ldx = Dp; d.x_f32 = 0; d.x_dtype_p1 = rt + 1; d.y16 = h16; d.ldy16 = Dp; d.gamma = g; d.beta = b;
+            d.eps = m->eps; d.rows = rows; d.cols = D; d.dtype = dt;
+            return tdc_layernorm(&d, stream);
+        };
+        {
+            tdc_rowmap cmap = {P, S, m->has_cls, 1}, rmap = {P, 0, m->has_cls, 1};
+            RET_IF(gemm_c16(patches, m->patch_lin.k, m->patch_lin, B * P, m->pos, m->ldpos, 1, cmap, rmap));
+        }
+        if (m->has_cls) RET_IF(tdc_set_rows16(x16, Dp, B, S, 0, m->cls_row, rt, stream));
+        for (int l = 0; l < m->n_layers; ++l) {
+            const tdc_vit_layer& L = m->layers_host[l];
+            RET_IF(ln16(L.ln1_g, L.ln1_b));
+            RET_IF(gemm(h16, Dp, L.qkv, qkv, L.qkv.n, rows, dt, TDC_ACT_NONE, 0, nullptr, 0, 0, ident, ident, stream));
+            tdc_attn_desc a;
+            memset(&a, 0, sizeof(a));
+            const long long bs = (long long)S * L.qkv.n;
+            a.q = qkv; a.k = qkv + (size_t)D * 2; a.v = qkv + (size_t)2 * D * 2; a.o = attn;
+            a.q_bs = a.k_bs = a.v_bs = bs; a.o_bs = (long long)S * Dp;
+            a.q_rs = a.k_rs = a.v_rs = L.qkv.n; a.o_rs = Dp;
+            a.batch = B; a.heads = m->heads; a.head_dim = m->head_dim; a.sq = S; a.sk = S; a.scale = scale; a.dtype = dt;
+            RET_IF(tdc_attention(&a, stream));
+            RET_IF(gemm_c16(attn, Dp, L.out, rows, x16, Dp, 0, ident, ident));
+            RET_IF(ln16(L.ln2_g, L.ln2_b));
+            RET_IF(gemm(h16, Dp, L.fc1, mlp, L.fc2.k, rows, dt, m->act, 0, nullptr, 0, 0, ident, ident, stream));
+            RET_IF(gemm_c16(mlp, L.fc2.k, L.fc2, rows, x16, Dp, 0, ident, ident));
+        }
+        const void* src16 = x16;
+        int src_dt = rt;
+        if (m->lnf_g) {
+            RET_IF(ln16(m->lnf_g, m->lnf_b));
+            src16 = h16;
+            src_dt = dt;
+        }
+        return tdc_resample_tokens(src16, 0, Dp, m->has_cls, g, out, ldo, out_grid, idx0, idx1, frac, B, D, src_dt, out_dt, stream);
+    }
     // fused: the block's LayerNorms are folded into the GEMMs around them (tdc_gemm_desc: x16 / ln_part / ln_stats / ln_c1);
     // h16 then holds the 16-bit copy of the residual stream instead of the LayerNorm output
     const bool fused = m->fused != 0;
@@ -442,8 +500,7 @@ extern "C" int tdc_vit_fwd(const tdc_vit_model* m, const void* px, int px_f32, i
         src = h16;
         src_f32 = 0;
     }
-    return tdc_resample_tokens(src, src_f32, Dp, m->has_cls, g, out, ldo, out_grid, idx0, idx1, frac, B, D, dt, m->out_dtype,
-                               stream);
+    return tdc_resample_tokens(src, src_f32, Dp, m->has_cls, g, out, ldo, out_grid, idx0, idx1, frac, B, D, dt, out_dt, stream);
 }
 
 // ---- connector (a6-a9) -------------------------------------------------------------------------------------------------

@@ -16,6 +16,7 @@
 #include "common.h"
 #include "../../include/tdc_hip.h"
 #include "attention_args.h"
+#include "profile.h"
 #include <stdio.h>
 #include <type_traits>
 
@@ -396,6 +397,8 @@ extern "C" int tdc_attention(const tdc_attn_desc* d, void* stream) {
     }
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype != TDC_F16 && d->dtype != TDC_BF16) return TDC_E_BADARG;
+    TdcProfScope prof(TDC_PROF_ATTN, st, d->batch * d->heads, d->sq, d->sk, d->head_dim, 0, 0, nullptr,
+                      4.0 * d->batch * d->heads * (double)d->sq * d->sk * d->head_dim);
     if (d->form != TDC_ATTN_FORM_16X16) {   // long sequences at head dim 64 / 72 (the towers): the 32x32x16 form
         const int rc = tdc_attention32(a, d->batch, d->dtype, st);
         if (rc != -1) return rc;

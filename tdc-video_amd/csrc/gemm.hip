@@ -15,6 +15,9 @@
 // (tile_m, tile_n): the tiles that share an activation row-panel run back to back on one L2.
 
 #include "gemm_impl.h"
+#ifndef TDC_GEMM_DIAG      // (the diagnostics tools compile this file by itself, without the profiler's translation unit)
+#include "profile.h"
+#endif
 
 // e4m3-operand instantiations live in gemm_fp8.hip (a translation unit of its own: the two compile in parallel)
 #ifdef TDC_GEMM_DIAG
@@ -63,7 +66,16 @@ extern "C" int tdc_gemm(const tdc_gemm_desc* d, void* stream) {
     if (d->c_pad8 && (d->out_f32 || d->res || d->bias || d->out_fp8 || d->act != TDC_ACT_NONE || d->c_map.seg != 0 ||
                       d->ldc < (d->N + 7) / 8 * 8))
         return TDC_E_BADARG;
+    if (d->c16_dtype_p1) {   /* C / 16-bit res of the other 16-bit type: plain 16-bit-output GEMMs (+ residual) only */
+        if (d->c16_dtype_p1 < 1 || d->c16_dtype_p1 > 2 || d->out_f32 || d->act != TDC_ACT_NONE || d->x16 || d->ln_stats ||
+            d->in_fp8 || d->out_fp8 || d->c_pad8)
+            return TDC_E_BADARG;
+    }
     hipStream_t st = (hipStream_t)stream;
+#ifndef TDC_GEMM_DIAG
+    TdcProfScope prof(TDC_PROF_GEMM, st, d->M, d->N, d->K, d->act, d->res ? (d->res_f32 ? 1 : 2) : 0, d->out_f32, d->W,
+                      2.0 * d->M * d->N * d->K);
+#endif
     if (d->out_fp8) {    /* e4m3 output: fp8 operands with their scales, whole 64-column wave tiles, 16-byte rows */
         if (!d->in_fp8 || !d->ln_stats || !d->out_stats || d->out_f32 || d->res || d->c_map.seg != 0 || d->N % 64 != 0 ||
             (d->ldc & 15) || d->ldc < (d->act == TDC_ACT_SWIGLU ? d->N / 2 : d->N) || ((uintptr_t)d->C & 15) ||

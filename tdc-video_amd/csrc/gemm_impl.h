@@ -36,6 +36,7 @@ struct GemmArgs {
     int debug;   // tdc_gemm_set_debug(): 1 = skip the epilogue, 2 = direct (un-staged) epilogue - timing experiments only
     int group_m;             // tile rows per group of the grouped tile order (tile_coords): 4 or 8, chosen per shape in launch()
     int c_pad8;              // tdc_gemm_desc.c_pad8: rows of C are writable up to round_up(N, 8) columns
+    int ctype;               // TDC_F16 / TDC_BF16: 16-bit type of C and of a 16-bit res (tdc_gemm_desc.c16_dtype_p1; default = T)
     // LayerNorm fusion (see EpiOps / slot_stats_*): producer side x16 + ln_part, consumer side ln_stats + ln_c1
     void* x16; int ldx16; float* ln_part;
     const float* ln_stats; const float* ln_c1;
@@ -209,7 +210,8 @@ __device__ __forceinline__ void slot_stats_mfma(const f32x4 (&v)[4], float& mean
 // Each lane holds, per (i, j) accumulator tile, 4 consecutive output columns n..n+3 of ONE output row m.  The epilogue
 // is specialised at compile time on (activation, residual kind, output type, LayerNorm fusion): the run-time flags select
 // one of the branch-free instantiations once per kernel.
-template <class T, int ACT, int RES, bool OUTF32>
+// TC: 16-bit type of C / of a 16-bit residual (T unless tdc_gemm_desc.c16_dtype_p1 says otherwise)
+template <class T, int ACT, int RES, bool OUTF32, class TC = T>
 __device__ __forceinline__ void epi_store(const GemmArgs& p, f32x4 v, long long crow, long long rrow, int n) {
     if (ACT == TDC_ACT_GELU_ERF) {
 #pragma unroll
@@ -233,18 +235,18 @@ __device__ __forceinline__ void epi_store(const GemmArgs& p, f32x4 v, long long 
     if (RES == 1) {
         v += *(const f32x4*)((const float*)p.res + rrow * p.ldres + n);
     } else if (RES == 2) {
-        typename VecOf<T>::v4 r = *(const typename VecOf<T>::v4*)((const T*)p.res + rrow * p.ldres + n);
+        typename VecOf<TC>::v4 r = *(const typename VecOf<TC>::v4*)((const TC*)p.res + rrow * p.ldres + n);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
     }
     if (OUTF32) {
         *(f32x4*)((float*)p.C + crow * p.ldc + n) = v;
     } else {
-        *(typename VecOf<T>::v4*)((T*)p.C + crow * p.ldc + n) = cvt4<T>(v);
+        *(typename VecOf<TC>::v4*)((TC*)p.C + crow * p.ldc + n) = cvt4<TC>(v);
     }
 }
 
-template <class T, int MI, int NJ, int ACT, int RES, bool OUTF32, bool LB, bool FOLD>
+template <class T, int MI, int NJ, int ACT, int RES, bool OUTF32, bool LB, bool FOLD, class TC = T>
 __device__ __forceinline__ void epi_tile(const GemmArgs& p, f32x4 (&acc)[MI][NJ], int mbase, int nbase, int fr,
                                          int g, const EpiLane& el) {
     EpiOps<MI, NJ, LB, FOLD> ops;
@@ -258,7 +260,7 @@ __device__ __forceinline__ void epi_tile(const GemmArgs& p, f32x4 (&acc)[MI][NJ]
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int n = nbase + j * 16 + g * 4;
-                if (n < p.N) epi_store<T, ACT, RES, OUTF32>(p, ops.lin(acc[i][j], i, j), crow, rrow, n);
+                if (n < p.N) epi_store<T, ACT, RES, OUTF32, TC>(p, ops.lin(acc[i][j], i, j), crow, rrow, n);
             }
         }
     }
@@ -383,8 +385,16 @@ __device__ __forceinline__ void epilogue_f(const GemmArgs& p, f32x4 (&acc)[MI][N
         else if (res == 2) epi_tile<T, MI, NJ, 0, 2, true, LB, false>(p, acc, mbase, nbase, fr, g, el);
         else epi_tile<T, MI, NJ, 0, 0, true, LB, false>(p, acc, mbase, nbase, fr, g, el);
     } else {
-        if (res == 1) epi_tile<T, MI, NJ, 0, 1, false, LB, false>(p, acc, mbase, nbase, fr, g, el);
-        else epi_tile<T, MI, NJ, 0, 2, false, LB, false>(p, acc, mbase, nbase, fr, g, el);
+        // 16-bit output with a residual: C / a 16-bit res may be of the other 16-bit type (GemmArgs::ctype)
+        typedef typename std::conditional<std::is_same<T, f16>::value, bf16, f16>::type TX;
+        const bool other = p.ctype != (std::is_same<T, f16>::value ? TDC_F16 : TDC_BF16);
+        if (res == 1) {
+            if (other) epi_tile<T, MI, NJ, 0, 1, false, LB, false, TX>(p, acc, mbase, nbase, fr, g, el);
+            else epi_tile<T, MI, NJ, 0, 1, false, LB, false>(p, acc, mbase, nbase, fr, g, el);
+        } else {
+            if (other) epi_tile<T, MI, NJ, 0, 2, false, LB, false, TX>(p, acc, mbase, nbase, fr, g, el);
+            else epi_tile<T, MI, NJ, 0, 2, false, LB, false>(p, acc, mbase, nbase, fr, g, el);
+        }
     }
 }
 
@@ -902,6 +912,105 @@ __device__ __forceinline__ void epi_staged32(const GemmArgs& p, f32x4 (&acc)[8][
     }
 }
 
+// 16-bit output + 16-bit residual (C = TC(acc + bias + float(res)), one rounding; in place when C == res): the read-modify-write
+// of a 16-bit residual stream - 4 B per element against the 8 B of the fp32 form - and the Q-Former's / connector's 16-bit
+// residual GEMMs.  The sub-tile is staged as fp32 (256-byte rows, the epi_staged32 image: chunk c of row r at c ^ (r & 15)); a
+// lane reads back 8 consecutive columns of one row (two 16-byte LDS reads), adds 8 residual values it loaded with ONE 16-byte
+// load, and stores 16 bytes: one wave instruction = 8 rows x 128 B on either side.  The residual loads run RING units (8 rows)
+// ahead of their use.  ROWS = rows staged per pass (16: 4 KiB region, 32: 8 KiB of the 16-KiB region).
+template <class TC, int ROWS, bool LB, int RING>
+__device__ __forceinline__ void epi_staged_rmw16(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase, int nbase,
+                                                 int lane, const EpiLane& el) {
+    typedef typename VecOf<TC>::v8 v8c;
+    typedef typename VecOf<TC>::v4 v4c;
+    const int fr = lane & 15, g = lane >> 4;
+    EpiOps<8, 4, LB, false> ops;
+    ops.load(p, mbase, nbase, fr, g, el);
+    constexpr int NPASS = 128 / ROWS, UP = ROWS / 8, NU = 16;     // unit = 8 rows x 64 columns = one 16-byte store per lane
+    const int rrow = lane >> 3, ck = lane & 7;
+    auto pack8 = [](f32x4 a, f32x4 b) {
+        const v4c x = cvt4<TC>(a), y = cvt4<TC>(b);
+        const u32x2 xr = __builtin_bit_cast(u32x2, x), yr = __builtin_bit_cast(u32x2, y);
+        return __builtin_bit_cast(v8c, (u32x4){xr[0], xr[1], yr[0], yr[1]});
+    };
+    if (p.cm.seg == 0 && p.rm.seg == 0 && mbase + 128 <= p.M && nbase + 64 <= p.N) {
+        // interior sub-tile, identity row maps: running pointers, straight-line passes (see epi_staged16 / epi_staged32)
+        const auto fops = opaque_ops(ops);
+        char* wbase = region + fr * 256;
+        const char* rbase = region + rrow * 256;
+        TC* cptr = (TC*)p.C + (long long)(mbase + rrow) * p.ldc + nbase + ck * 8;
+        const TC* rptr = (const TC*)p.res + (long long)(mbase + rrow) * p.ldres + nbase + ck * 8;
+        const long long cstep = 8ll * p.ldc, rstep = 8ll * p.ldres;
+        v8c ring[RING];
+#pragma unroll
+        for (int u = 0; u < RING; ++u) { ring[u] = *(const v8c*)rptr; rptr += rstep; }
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+            for (int ii = 0; ii < ROWS / 16; ++ii) {
+                const int i = pass * (ROWS / 16) + ii;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *(f32x4*)(wbase + ii * 4096 + (((j * 4 + g) ^ fr) << 4)) = fops.lin(acc[i][j], i, j);
+            }
+            f32x4 lo[UP], hi[UP];
+#pragma unroll
+            for (int q = 0; q < UP; ++q) {
+                const int r = q * 8 + rrow;
+                lo[q] = *(const f32x4*)(rbase + q * 2048 + (((2 * ck) ^ (r & 15)) << 4));
+                hi[q] = *(const f32x4*)(rbase + q * 2048 + (((2 * ck + 1) ^ (r & 15)) << 4));
+            }
+#pragma unroll
+            for (int q = 0; q < UP; ++q) {
+                const int u = pass * UP + q;
+                const v8c rr = ring[u % RING];
+                if (u + RING < NU) { ring[u % RING] = *(const v8c*)rptr; rptr += rstep; }
+                f32x4 a = lo[q], b = hi[q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a[e] += (float)rr[e]; b[e] += (float)rr[4 + e]; }
+                __builtin_nontemporal_store(pack8(a, b), (v8c*)cptr);
+                cptr += cstep;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
+    // general form: row maps, partial tiles (clamped residual loads, guarded stores)
+    auto load_res = [&](int u) {
+        int m = mbase + u * 8 + rrow, n = nbase + ck * 8;
+        if (m > p.M - 1) m = p.M - 1;
+        if (n > p.N - 8) n = p.N - 8;
+        return *(const v8c*)((const TC*)p.res + p.rm(m) * p.ldres + n);
+    };
+    v8c rr[RING];
+#pragma unroll
+    for (int u = 0; u < RING; ++u) rr[u] = load_res(u);
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+        for (int ii = 0; ii < ROWS / 16; ++ii) {
+            const int i = pass * (ROWS / 16) + ii;
+            const int r = ii * 16 + fr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *(f32x4*)(region + r * 256 + (((j * 4 + g) ^ (r & 15)) << 4)) = ops.lin(acc[i][j], i, j);
+        }
+#pragma unroll
+        for (int q = 0; q < UP; ++q) {
+            const int u = pass * UP + q;
+            const int r = q * 8 + rrow;
+            f32x4 a = *(const f32x4*)(region + r * 256 + (((2 * ck) ^ (r & 15)) << 4));
+            f32x4 b = *(const f32x4*)(region + r * 256 + (((2 * ck + 1) ^ (r & 15)) << 4));
+            const v8c x = rr[u % RING];
+            if (u + RING < NU) rr[u % RING] = load_res(u + RING);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] += (float)x[e]; b[e] += (float)x[4 + e]; }
+            const int m = mbase + pass * ROWS + r, n = nbase + ck * 8;
+            if (m < p.M && n < p.N) __builtin_nontemporal_store(pack8(a, b), (v8c*)((TC*)p.C + p.cm(m) * p.ldc + n));
+        }
+    }
+}
+
 // returns false when this (act, res, out) combination / alignment has no staged variant.  SMALL: 4 KiB staging region
 // per wave (the persistent kernel stages beside the live pipeline buffers, lane-held operands), otherwise 16 KiB.
 template <class T, bool SMALL, bool FOLD>
@@ -932,7 +1041,12 @@ __device__ __forceinline__ bool epilogue_staged_f(const GemmArgs& p, f32x4 (&acc
     if ((p.N & 7) && !(p.c_pad8 && !(p.N & 3))) return false;   // 16-byte stores of 8 columns: the last group may overhang N by 4
     if (p.act == TDC_ACT_GELU_ERF) epi_staged16<T, TDC_ACT_GELU_ERF, 0, R16, SMALL, FOLD>(p, acc, region, mbase, nbase, lane, el);
     else if (p.act == TDC_ACT_GELU_TANH) epi_staged16<T, TDC_ACT_GELU_TANH, 0, R16, SMALL, FOLD>(p, acc, region, mbase, nbase, lane, el);
-    else if (res == 2) { if (FOLD) return false; epi_staged16<T, 0, 2, R16, SMALL, false>(p, acc, region, mbase, nbase, lane, el); }
+    else if (res == 2) {
+        if (FOLD || (p.N & 7) || (p.ldres & 7) || ((uintptr_t)p.res & 15)) return false;
+        constexpr int RR = SMALL ? 16 : 32;
+        if (p.ctype == TDC_F16) epi_staged_rmw16<f16, RR, SMALL, 8>(p, acc, region, mbase, nbase, lane, el);
+        else epi_staged_rmw16<bf16, RR, SMALL, 8>(p, acc, region, mbase, nbase, lane, el);
+    }
     else epi_staged16<T, 0, 0, R16, SMALL, FOLD>(p, acc, region, mbase, nbase, lane, el);
     return true;
 }
@@ -1528,6 +1642,7 @@ int launch(const tdc_gemm_desc* d, hipStream_t st, bool force128 = false) {
     a.debug = tdc_gemm_debug_mode;
     a.group_m = GROUP_M_DEFAULT;
     a.c_pad8 = d->c_pad8;
+    a.ctype = d->c16_dtype_p1 ? d->c16_dtype_p1 - 1 : d->dtype;
 #ifdef TDC_GEMM_DIAG
     { const char* e = getenv("TDC_GEMM_DIAGMODE"); a.diag_mode = e ? atoi(e) : 0; }
 #endif

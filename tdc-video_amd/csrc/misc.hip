@@ -291,6 +291,22 @@ extern "C" int tdc_set_rows(float* x32, int ld, int B, int S, int row, const flo
     return (int)hipGetLastError();
 }
 
+namespace {
+template <class T>
+__global__ void set_rows16_kernel(T* x, int ld, int S, int row, const float* vec) {
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < ld; c += blockDim.x) x[((long long)b * S + row) * ld + c] = (T)vec[c];
+}
+}  // namespace
+
+extern "C" int tdc_set_rows16(void* x16, int ld, int B, int S, int row, const float* vec, int dtype, void* stream) {
+    if (!x16 || !vec || B <= 0) return TDC_E_BADARG;
+    if (dtype == TDC_F16) hipLaunchKernelGGL(set_rows16_kernel<f16>, dim3(B), dim3(256), 0, (hipStream_t)stream, (f16*)x16, ld, S, row, vec);
+    else if (dtype == TDC_BF16) hipLaunchKernelGGL(set_rows16_kernel<bf16>, dim3(B), dim3(256), 0, (hipStream_t)stream, (bf16*)x16, ld, S, row, vec);
+    else return TDC_E_BADARG;
+    return (int)hipGetLastError();
+}
+
 extern "C" int tdc_resample_tokens(const void* x, int x_f32, int ldx, int tok_off, int n_in, void* y, int ldy,
                                    int n_out, const int* idx0, const int* idx1, const float* frac, int B, int cols,
                                    int dtype, int out_dtype, void* stream) {

@@ -1,6 +1,7 @@
 // LayerNorm / L2-normalise / Q-Former embedding+LN: HBM-bound row kernels, one wave per row, fp32 statistics.
 #include "common.h"
 #include "../../include/tdc_hip.h"
+#include "profile.h"
 #include <stdio.h>
 
 namespace {
@@ -137,6 +138,79 @@ int launch_ln(const LnArgs& a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+// 16-bit rows in, 16-bit rows out (the towers' LayerNorms over a 16-bit residual stream, tdc_vit_model.res_dtype_p1): 4 B per
+// element instead of 6, every access 16 bytes per lane (lane l owns columns 8 (l + 64 i) .. + 7).  TI / TO: input / output type
+// (an fp16 stream normalised into bf16 GEMM operands).  Same arithmetic as ln_kernel: fp32 statistics, two passes over the
+// register-held row.
+template <class TI, class TO, int NV8>
+__global__ __launch_bounds__(256) void ln16_kernel(LnArgs p) {
+    typedef typename VecOf<TI>::v8 v8i;
+    typedef typename VecOf<TO>::v4 v4o;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const long long xrow = p.xm(row), yrow = p.ym(row);
+    float v[NV8][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV8; ++i) {
+        const int c = (lane + i * 64) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+        if (c < p.cols) {
+            const v8i h = __builtin_nontemporal_load((const v8i*)((const TI*)p.x + xrow * p.ldx + c));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[i][e] = (float)h[e];
+        }
+        s += ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) + ((v[i][4] + v[i][5]) + (v[i][6] + v[i][7]));
+    }
+    s = wave_sum(s);
+    const float mean = s / (float)p.cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV8; ++i) {
+        const int c = (lane + i * 64) * 8;
+        if (c < p.cols) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+    }
+    q = wave_sum(q);
+    const float rstd = rsqrtf(q / (float)p.cols + p.eps);
+#pragma unroll
+    for (int i = 0; i < NV8; ++i) {
+        const int c = (lane + i * 64) * 8;
+        if (c < p.pad_cols) {
+            f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
+            if (c < p.cols) {
+                const f32x4 g0 = *(const f32x4*)(p.gamma + c), g1 = *(const f32x4*)(p.gamma + c + 4);
+                const f32x4 b0 = *(const f32x4*)(p.beta + c), b1 = *(const f32x4*)(p.beta + c + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o0[e] = (v[i][e] - mean) * rstd * g0[e] + b0[e];
+                    o1[e] = (v[i][4 + e] - mean) * rstd * g1[e] + b1[e];
+                }
+            }
+            const v4o x = cvt4<TO>(o0), y = cvt4<TO>(o1);
+            const u32x2 xr = __builtin_bit_cast(u32x2, x), yr = __builtin_bit_cast(u32x2, y);
+            *(u32x4*)((TO*)p.y16 + yrow * p.ldy16 + c) = (u32x4){xr[0], xr[1], yr[0], yr[1]};
+        }
+    }
+}
+
+template <class TI, class TO>
+int launch_ln16(const LnArgs& a, hipStream_t st) {
+    const int nv = (a.pad_cols + 511) / 512;
+    dim3 grid((a.rows + 3) / 4), block(256);
+    if (nv <= 1) hipLaunchKernelGGL((ln16_kernel<TI, TO, 1>), grid, block, 0, st, a);
+    else if (nv <= 2) hipLaunchKernelGGL((ln16_kernel<TI, TO, 2>), grid, block, 0, st, a);
+    else if (nv <= 3) hipLaunchKernelGGL((ln16_kernel<TI, TO, 3>), grid, block, 0, st, a);
+    else if (nv <= 4) hipLaunchKernelGGL((ln16_kernel<TI, TO, 4>), grid, block, 0, st, a);
+    else if (nv <= 8) hipLaunchKernelGGL((ln16_kernel<TI, TO, 8>), grid, block, 0, st, a);
+    else return TDC_E_BADARG;
+    return (int)hipGetLastError();
+}
+
 // ---- L2 normalise in place --------------------------------------------------------------------------------
 template <class T>
 __global__ __launch_bounds__(256) void l2n_kernel(T* x, int ld, int rows, int cols) {
@@ -243,9 +317,19 @@ extern "C" int tdc_layernorm(const tdc_ln_desc* d, void* stream) {
         return TDC_E_BADARG;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (d->dtype != TDC_F16 && d->dtype != TDC_BF16) return TDC_E_BADARG;
+    TdcProfScope prof(TDC_PROF_LN, st, d->rows, d->cols, 0, 0, 0, 0, nullptr, 0.0);
+    if (d->x_dtype_p1) {
+        // 16-bit input of its own type -> 16-bit output (ln16_kernel): 16-byte accesses on both sides
+        const int xt = d->x_dtype_p1 - 1;
+        if (d->x_f32 || (xt != TDC_F16 && xt != TDC_BF16) || !d->y16 || d->y32 || d->y8 || d->add || (d->cols & 7) ||
+            (d->ldx & 7) || (d->ldy16 & 7) || (a.pad_cols & 7) || ((uintptr_t)d->x & 15) || ((uintptr_t)d->y16 & 15))
+            return TDC_E_BADARG;
+        if (xt == TDC_F16) return d->dtype == TDC_F16 ? launch_ln16<f16, f16>(a, st) : launch_ln16<f16, bf16>(a, st);
+        return d->dtype == TDC_F16 ? launch_ln16<bf16, f16>(a, st) : launch_ln16<bf16, bf16>(a, st);
+    }
     if (d->dtype == TDC_F16) return launch_ln<f16>(a, st);
-    if (d->dtype == TDC_BF16) return launch_ln<bf16>(a, st);
-    return TDC_E_BADARG;
+    return launch_ln<bf16>(a, st);
 }
 
 extern "C" int tdc_l2_normalize(void* x, int ld, int rows, int cols, int dtype, void* stream) {

@@ -28,6 +28,7 @@
 //                 LDS), fp32 + 16-bit rows stored.
 #include "common.h"
 #include "../../include/tdc_hip.h"
+#include "profile.h"
 #include <stdio.h>
 #include <type_traits>
 
@@ -583,7 +584,7 @@ extern "C" int tdc_qformer_xattn(const tdc_xattn_desc* d, void* stream) {
         return TDC_E_BADARG;
     if (out_only) {
         if (d->ldctx % 8 || d->ldctx < XD || !al(d->ctx, 16)) return TDC_E_BADARG;
-    } else if (d->ldk % 8 || d->ldk < XD || d->ldvt % 4 || d->ldvt < (long long)d->F * d->Nenc || !al(d->wq, 16) || !al(d->k, 16) ||
+    } else if (d->ldk % 8 || d->ldk < XD || d->ldvt % 4 || d->ldvt < ((long long)d->F * d->Nenc + 7) / 8 * 8 || !al(d->wq, 16) || !al(d->k, 16) ||
                !al(d->vt, 8) || !al(d->bq, 16) || (d->bv && !al(d->bv, 16))) {
         return TDC_E_BADARG;
     }
@@ -599,6 +600,9 @@ extern "C" int tdc_qformer_xattn(const tdc_xattn_desc* d, void* stream) {
     a.nblocks = (a.rows + XROWS - 1) / XROWS;
     const int nkt = (d->Nenc + 15) / 16;
     hipStream_t st = (hipStream_t)stream;
+    const double rows = (double)d->F * d->K;
+    TdcProfScope prof(TDC_PROF_XATTN, st, d->F * d->K, d->Nenc, 0, out_only ? 1 : 0, 0, 0, nullptr,
+                      out_only ? 2.0 * rows * d->dim * d->dim : 4.0 * rows * d->dim * d->dim + 4.0 * rows * d->Nenc * d->dim);
     if (d->dtype == TDC_F16) return launch<f16>(a, nkt, st);
     if (d->dtype == TDC_BF16) return launch<bf16>(a, nkt, st);
     return TDC_E_BADARG;

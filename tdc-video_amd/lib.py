@@ -23,7 +23,7 @@ class GemmDesc(C.Structure):
                 ("x16", C.c_void_p), ("ldx16", C.c_int), ("ln_part", C.c_void_p),
                 ("ln_stats", C.c_void_p), ("ln_c1", C.c_void_p), ("in_fp8", C.c_int),
                 ("out_fp8", C.c_int), ("out_stats", C.c_void_p), ("out_w2max", C.c_float), ("out_bmax", C.c_float),
-                ("out_wscale", C.c_float), ("c_pad8", C.c_int)]
+                ("out_wscale", C.c_float), ("c_pad8", C.c_int), ("c16_dtype_p1", C.c_int)]
 
 
 class LnDesc(C.Structure):
@@ -33,7 +33,8 @@ class LnDesc(C.Structure):
                 ("add", C.c_void_p), ("ldadd", C.c_int), ("add_period", C.c_int), ("add_mode", C.c_int),
                 ("rows", C.c_int), ("cols", C.c_int), ("dtype", C.c_int),
                 ("x_map", RowMap), ("y_map", RowMap),
-                ("y8", C.c_void_p), ("ldy8", C.c_int), ("y8_stats", C.c_void_p), ("y8_wscale", C.c_float)]
+                ("y8", C.c_void_p), ("ldy8", C.c_int), ("y8_stats", C.c_void_p), ("y8_wscale", C.c_float),
+                ("x_dtype_p1", C.c_int)]
 
 
 class AttnDesc(C.Structure):
@@ -84,7 +85,8 @@ class VitModel(C.Structure):
                 ("n_layers", C.c_int), ("patch", C.c_int), ("has_cls", C.c_int), ("act", C.c_int),
                 ("eps", C.c_float), ("patch_lin", Lin), ("pos", C.c_void_p), ("ldpos", C.c_int),
                 ("cls_row", C.c_void_p), ("lnf_g", C.c_void_p), ("lnf_b", C.c_void_p),
-                ("layers_host", C.POINTER(VitLayer)), ("fused", C.c_int), ("fp8", C.c_int), ("out_dtype", C.c_int)]
+                ("layers_host", C.POINTER(VitLayer)), ("fused", C.c_int), ("fp8", C.c_int), ("out_dtype_p1", C.c_int),
+                ("res_dtype_p1", C.c_int)]
 
 
 class AuxProj(C.Structure):
@@ -133,6 +135,14 @@ class XattnDesc(C.Structure):
                 ("ctx", C.c_void_p), ("ldctx", C.c_int), ("res16", C.c_int)]
 
 
+class ProfRec(C.Structure):
+    _fields_ = [("kind", C.c_int), ("tag", C.c_int), ("ms", C.c_float), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("act", C.c_int), ("res", C.c_int), ("out_f32", C.c_int), ("W", C.c_void_p), ("flops", C.c_double)]
+
+
+PROF_GEMM, PROF_ATTN, PROF_LN, PROF_XATTN = 1, 2, 3, 4
+PROF_TAG_XATTN_BLOCK = 1
+
 # name -> (restype, argtypes); every symbol include/tdc_hip.h declares
 SIGNATURES = {
     "tdc_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
@@ -145,6 +155,7 @@ SIGNATURES = {
     "tdc_im2col": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_void_p]),
     "tdc_set_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "tdc_set_rows16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "tdc_resample_tokens": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "tdc_frame_cossim": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
@@ -181,6 +192,9 @@ SIGNATURES = {
                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "tdc_relpos_gate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "tdc_profile_start": (C.c_int, [C.c_int]),
+    "tdc_profile_stop": (C.c_int, [C.POINTER(ProfRec), C.c_int]),
+    "tdc_profile_tag": (C.c_int, [C.c_int]),
     "tdc_version": (C.c_char_p, []),
     "tdc_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
 }

@@ -9,28 +9,44 @@ import torch
 from . import lib as L
 
 
-# bench.py sets PROFILE to a dict to time kernels with events on the launch stream: {"gemm": [(e0, e1, flops)], ...}
-PROFILE = None
-# a launch made while TAG is set is also recorded under PROFILE["tag:" + TAG] (the Q-Former cross-attention block's launches)
-TAG = None
+# ---- launch profiler (tdc_profile_* of the C ABI): events are recorded INSIDE the library, around every tdc_gemm /
+# tdc_attention / tdc_layernorm / tdc_qformer_xattn launch, whether it comes from a wrapper below or from inside a composite
+# (tdc_vit_fwd, tdc_connector_fwd, tdc_qformer_fwd): bench.py's profiled step runs the same host path as its timed steps.
+REAL_NK = {}      # weight data_ptr -> un-padded (n, k) of a prepared weight (weights.py), for algorithmic FLOP counts
 
 
-def _prof_begin(kind):
-    if PROFILE is None or kind not in PROFILE:
-        return None
-    e0 = torch.cuda.Event(enable_timing=True)
-    e0.record()
-    return e0
+def register_real_nk(w, n, k):
+    w._real_nk = (n, k)
+    REAL_NK[w.data_ptr()] = (n, k)
 
 
-def _prof_end(kind, e0, work):
-    if e0 is None:
-        return
-    e1 = torch.cuda.Event(enable_timing=True)
-    e1.record()
-    PROFILE[kind].append((e0, e1, work))
-    if TAG is not None and "tag:" + TAG in PROFILE:
-        PROFILE["tag:" + TAG].append((e0, e1, work, kind))
+def profile_start(max_records=1 << 15):
+    L.check(L.load().tdc_profile_start(int(max_records)), "tdc_profile_start")
+
+
+def profile_tag(tag):
+    return L.load().tdc_profile_tag(int(tag))
+
+
+def profile_stop(max_records=1 << 15):
+    """-> list of dicts, one per launch in launch order: kind ('gemm' | 'attn' | 'ln' | 'xattn'), tag, ms, M, N, K, act, res,
+    out_f32, flops (GEMMs: from the un-padded weight dims when the weight is registered)."""
+    recs = (L.ProfRec * max_records)()
+    n = L.load().tdc_profile_stop(recs, max_records)
+    if n < 0:
+        raise L.TdcHipError("tdc_profile_stop failed with code %d" % n)
+    assert n <= max_records, "profile table too small: %d launches" % n
+    kinds = {L.PROF_GEMM: "gemm", L.PROF_ATTN: "attn", L.PROF_LN: "ln", L.PROF_XATTN: "xattn"}
+    out = []
+    for r in recs[:n]:
+        fl = r.flops
+        if r.kind == L.PROF_GEMM and r.W in REAL_NK:
+            rn, rk = REAL_NK[r.W]
+            if rn <= r.N and rk <= r.K:         # (a stale pointer whose address an activation buffer reuses does not qualify)
+                fl = 2.0 * r.M * rn * rk
+        out.append(dict(kind=kinds.get(r.kind, "?"), tag=r.tag, ms=r.ms, M=r.M, N=r.N, K=r.K, act=r.act, res=r.res,
+                        out_f32=r.out_f32, flops=fl))
+    return out
 
 
 def _dt(t):
@@ -120,6 +136,10 @@ def gemm(a, w, bias=None, act=L.ACT_NONE, res=None, out=None, out_f32=False, M=N
     else:
         assert (out.dtype == torch.float32) == bool(out_f32)
     d = L.GemmDesc()
+    if not fp8 and not out_f32 and out.dtype != out_dtype:
+        # C (and a 16-bit res) of the other 16-bit type: tdc_gemm_desc.c16_dtype_p1 (an fp16 residual stream under bf16 operands)
+        assert out.dtype in (torch.float16, torch.bfloat16) and act == L.ACT_NONE
+        d.c16_dtype_p1 = _dtcode(out.dtype) + 1
     d.A, d.lda = a.data_ptr(), a.stride(0)
     d.W, d.ldw = w.data_ptr(), w.stride(0)
     d.C, d.ldc = out.data_ptr(), out.stride(0)
@@ -132,7 +152,7 @@ def gemm(a, w, bias=None, act=L.ACT_NONE, res=None, out=None, out_f32=False, M=N
         d.res, d.ldres = res.data_ptr(), res.stride(0)
         d.res_f32 = 1 if res.dtype == torch.float32 else 0
         if not d.res_f32:
-            assert res.dtype == a.dtype
+            assert res.dtype == out.dtype, "a 16-bit residual has the type of the 16-bit output"
     d.M, d.N, d.K = M, N, K
     d.dtype, d.out_f32, d.act = _dtcode(out_dtype), int(out_f32), act
     d.in_fp8 = int(fp8)
@@ -154,13 +174,7 @@ def gemm(a, w, bias=None, act=L.ACT_NONE, res=None, out=None, out_f32=False, M=N
     if c_pad8:      # rows of `out` writable up to round_up(N, 8) columns (tdc_gemm_desc.c_pad8)
         assert bias is None and res is None and not out_f32 and act == L.ACT_NONE and out.shape[1] >= (N + 7) // 8 * 8
         d.c_pad8 = 1
-    e0 = _prof_begin("gemm")
     L.check(L.load().tdc_gemm(C.byref(d), _stream()), "tdc_gemm")
-    if e0 is not None:
-        rn, rk = getattr(w, "_real_nk", (N, K))
-        _prof_end("gemm", e0, 2.0 * M * rn * rk)
-        if "gemm_shapes" in PROFILE:
-            PROFILE["gemm_shapes"].append((M, N, K, act, int(res is not None), int(out_f32)))
     return out
 
 
@@ -193,7 +207,8 @@ def quantize_rows_fp8(x, cols, wscale, y8=None, stats=None):
 
 
 def layernorm(x, gamma, beta, eps, cols, dtype, y16=None, y32=None, add=None, add_period=0, add_mode=0,
-              want16=True, want32=False, rows=None, x_map=None, y_map=None, y8=None, y8_stats=None, y8_wscale=1.0):
+              want16=True, want32=False, rows=None, x_map=None, y_map=None, y8=None, y8_stats=None, y8_wscale=1.0,
+              x16_kernel=False):
     """LayerNorm over the first `cols` columns of x [rows, ld] (fp32 or 16-bit) -> (y16, y32).  y8 [rows, ld] uint8 +
     y8_stats [rows, 2]: e4m3 output with per-row scales for an fp8-operand GEMM (include/tdc_hip.h)."""
     if y8 is not None:
@@ -211,6 +226,10 @@ def layernorm(x, gamma, beta, eps, cols, dtype, y16=None, y32=None, add=None, ad
     d = L.LnDesc()
     d.x_map, d.y_map = _map(x_map), _map(y_map)
     d.x, d.ldx, d.x_f32 = x.data_ptr(), x.stride(0), int(x.dtype == torch.float32)
+    if x.dtype != torch.float32 and (x.dtype != dtype or x16_kernel):
+        # 16-bit input of its own type through the 16-bit-to-16-bit kernel (tdc_ln_desc.x_dtype_p1)
+        assert y32 is None and y8 is None and add is None and cols % 8 == 0
+        d.x_dtype_p1 = _dtcode(x.dtype) + 1
     if y16 is not None:
         assert y16.shape[0] > ymax and y16.shape[1] >= cols and y16.dtype == dtype
         d.y16, d.ldy16 = y16.data_ptr(), y16.stride(0)
@@ -229,9 +248,7 @@ def layernorm(x, gamma, beta, eps, cols, dtype, y16=None, y32=None, add=None, ad
         assert y8_stats is not None and y8_stats.dtype == torch.float32 and y8_stats.is_contiguous()
         assert y8_stats.numel() >= 2 * (ymax + 1)
         d.y8, d.ldy8, d.y8_stats, d.y8_wscale = y8.data_ptr(), y8.stride(0), y8_stats.data_ptr(), float(y8_wscale)
-    e0 = _prof_begin("ln")
     L.check(L.load().tdc_layernorm(C.byref(d), _stream()), "tdc_layernorm")
-    _prof_end("ln", e0, 0.0)
     return y16, y32
 
 
@@ -269,9 +286,7 @@ def attention(q, k, v, out, batch, heads, head_dim, sq, sk, scale, q_bs, k_bs, v
         assert key_mask.is_cuda and key_mask.dtype in (torch.uint8, torch.bool) and key_mask.is_contiguous()
         assert tuple(key_mask.shape) == (batch, sk)
         d.key_mask, d.key_mask_bs = key_mask.data_ptr(), sk
-    e0 = _prof_begin("attn")
     L.check(L.load().tdc_attention(C.byref(d), _stream()), "tdc_attention")
-    _prof_end("attn", e0, 4.0 * batch * heads * sq * sk * head_dim)
     return out
 
 
@@ -298,6 +313,13 @@ def im2col(px, patch, dtype):
 def set_rows(x32, B, S, row, vec):
     assert x32.dtype == torch.float32 and x32.dim() == 2 and x32.shape[0] >= B * S and vec.numel() >= x32.shape[1]
     L.check(L.load().tdc_set_rows(_ptr(x32), x32.stride(0), B, S, row, _ptr(vec), _stream()), "tdc_set_rows")
+
+
+def set_rows16(x16, B, S, row, vec):
+    assert x16.dtype in (torch.float16, torch.bfloat16) and x16.dim() == 2 and x16.shape[0] >= B * S
+    assert vec.dtype == torch.float32 and vec.numel() >= x16.shape[1]
+    L.check(L.load().tdc_set_rows16(_ptr(x16), x16.stride(0), B, S, row, _ptr(vec), _dtcode(x16.dtype), _stream()),
+            "tdc_set_rows16")
 
 
 def bilinear_tables(n_in, n_out, device):
@@ -497,9 +519,7 @@ def qformer_xattn_out(h16, h32, F, K, S, ctx, wo_t, bo, ln_g, ln_b, eps, dim, he
     d.ln_g, d.ln_b, d.eps = ln_g.data_ptr(), ln_b.data_ptr(), eps
     d.dim, d.heads, d.dtype, d.Nenc = dim, heads, _dt(h16), 8
     d.ctx, d.ldctx = ctx.data_ptr(), ctx.stride(0)
-    e0 = _prof_begin("xattn")
     L.check(L.load().tdc_qformer_xattn(C.byref(d), _stream()), "tdc_qformer_xattn")
-    _prof_end("xattn", e0, 2.0 * F * K * dim * dim)
 
 
 def qformer_xattn(h16, h32, F, K, S, wq_t, bq, wo_t, bo, k, vt, bv, Nenc, ln_g, ln_b, eps, dim, heads, scale):
@@ -525,9 +545,7 @@ def qformer_xattn(h16, h32, F, K, S, wq_t, bq, wo_t, bo, k, vt, bv, Nenc, ln_g, 
     d.vt, d.ldvt, d.bv = vt.data_ptr(), vt.stride(0), bv.data_ptr() if bv is not None else None
     d.Nenc, d.ln_g, d.ln_b, d.eps = Nenc, ln_g.data_ptr(), ln_b.data_ptr(), eps
     d.dim, d.heads, d.scale, d.dtype = dim, heads, scale, _dt(h16)
-    e0 = _prof_begin("xattn")
     L.check(L.load().tdc_qformer_xattn(C.byref(d), _stream()), "tdc_qformer_xattn")
-    _prof_end("xattn", e0, 4.0 * F * K * dim * dim + 4.0 * F * K * Nenc * dim)
 
 
 def fbank(wav, tables, dtype, want_plain=False, mean=15.41663, std=6.55582):

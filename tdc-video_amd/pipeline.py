@@ -48,7 +48,8 @@ class _LRU(dict):
 
 class VideoEncoder:
     def __init__(self, sd, cfg, dtype=torch.float16, device="cuda", siglip_heads=16, dino_heads=24,
-                 qformer_heads=12, tower_batch=64, fp8_towers=False, tower_dtype=None, ln_fuse=False):
+                 qformer_heads=12, tower_batch=64, fp8_towers=False, tower_dtype=None, ln_fuse=False,
+                 tower_res_dtype=None):
         """sd: reference-named state dict without the leading 'model.'; cfg: dict of reference config keys.
         dtype: 16-bit type of the connector, the Q-Former and every tensor handed to the caller; tower_dtype (default:
         dtype): 16-bit type of the two ViT towers - their last kernel (the token-grid resample) writes `dtype` rows.  bf16
@@ -56,8 +57,15 @@ class VideoEncoder:
         1.0e-4 at full depth; all-bf16: 6e-4 ... 2e-3): the 16-bit error of the context tokens is made behind the towers.
         fp8_towers (BASELINE config 5): the towers' LayerNorms emit e4m3 rows with per-row scales and the qkv / fc1 GEMMs
         run on fp8 operands (v_mfma_f32_16x16x128_f8f6f4); everything else stays in `tower_dtype`.
-        ln_fuse: the towers' pre-LayerNorms folded into the neighbouring GEMMs (weights.ln_fusion_enabled; off by default)."""
+        ln_fuse: the towers' pre-LayerNorms folded into the neighbouring GEMMs (weights.ln_fusion_enabled; off by default).
+        tower_res_dtype: type of the towers' residual stream in HBM - None / torch.float32: fp32 (the out-projection / fc2
+        epilogues read-modify-write 8 B per element); torch.float16 (or bfloat16): that 16-bit type - 4 B per element, half
+        the LayerNorm input bytes, sums formed in fp32 and rounded once per residual add.  fp16 is the reference's own
+        arithmetic (its HF towers run under torch_dtype=float16, tdc/builder.py:69).  Not with fp8_towers / ln_fuse."""
         self.cfg = dict(cfg)
+        self.tower_res_dtype = None if tower_res_dtype in (None, torch.float32) else tower_res_dtype
+        assert self.tower_res_dtype in (None, torch.float16, torch.bfloat16)
+        assert self.tower_res_dtype is None or not (fp8_towers or ln_fuse)
         self.dtype, self.dev = dtype, torch.device(device)
         self._tower_dtype = tower_dtype = dtype if tower_dtype is None else tower_dtype
         self.tower_batch = tower_batch
@@ -130,7 +138,9 @@ class VideoEncoder:
                                    zeros.data_ptr() if zeros is not None else None,
                                    Lr.out.wscale or 0.0, Lr.fc2.wscale or 0.0, Lr.fc1.w2max, Lr.fc1.bmax)
         m = L.VitModel()
-        m.dtype, m.out_dtype = ops._dtcode(self.tower_dtype), ops._dtcode(self.dtype)
+        m.dtype, m.out_dtype_p1 = ops._dtcode(self.tower_dtype), ops._dtcode(self.dtype) + 1
+        rd = getattr(self, "tower_res_dtype", None)
+        m.res_dtype_p1 = 0 if rd is None else ops._dtcode(rd) + 1
         m.dim, m.heads, m.head_dim, m.n_layers, m.patch, m.has_cls = t.dim, t.heads, t.head_dim, len(t.layers), t.patch, \
             t.has_cls
         m.act = {"gelu_tanh": L.ACT_GELU_TANH, "gelu_erf": L.ACT_GELU_ERF, "swiglu": L.ACT_SWIGLU}[t.act]
@@ -170,9 +180,12 @@ class VideoEncoder:
         return out
 
     def _tower_batch(self, t, px, out_grid):
-        if getattr(self, "native_towers", True) and ops.PROFILE is None and len(t.layers) > 0:
+        if getattr(self, "native_towers", True) and len(t.layers) > 0:
             return self._tower_batch_native(t, px, out_grid)
         dt, dev = self.tower_dtype, self.dev
+        rd = getattr(self, "tower_res_dtype", None)
+        if rd is not None:
+            return self._tower_batch_res16(t, px, out_grid, rd)
         B = px.shape[0]
         D, Dp = t.dim, pad64(t.dim)
         patches, gh, gw = ops.im2col(px, t.patch, dt)
@@ -259,6 +272,43 @@ class VideoEncoder:
             ops.layernorm(x32, t.final_ln[0], t.final_ln[1], t.eps, D, dt, y16=h16)
             src = h16
         return ops.resample_tokens(src, B, t.has_cls, gh, out_grid, D, dt, self._bil(gh, out_grid), out_dtype=self.dtype)
+
+    def _tower_batch_res16(self, t, px, out_grid, rd):
+        """per-kernel sequence of a tower batch over a 16-bit residual stream of type `rd` (== tdc_vit_fwd with res_dtype_p1)"""
+        dt, dev = self.tower_dtype, self.dev
+        B = px.shape[0]
+        D, Dp = t.dim, pad64(t.dim)
+        patches, gh, gw = ops.im2col(px, t.patch, dt)
+        assert gh == gw, "square inputs only (reference pads to square, mm_datautils.py:286-314)"
+        P = gh * gw
+        S = P + t.has_cls
+        pos, cls_row = Wt.tower_pos(t, gh, gw, dev)
+        x16 = torch.empty(B * S, Dp, device=dev, dtype=rd)
+        ops.gemm(patches, t.patch_lin.w, t.patch_lin.b, res=pos, r_map=(P, 0, t.has_cls, 1), out=x16,
+                 c_map=(P, S, t.has_cls, 1))
+        if t.has_cls:
+            ops.set_rows16(x16, B, S, 0, cls_row)
+        h16 = torch.empty(B * S, Dp, device=dev, dtype=dt)
+        qkv = torch.empty(B * S, t.layers[0].qkv.w.shape[0], device=dev, dtype=dt)
+        attn = torch.zeros(B * S, Dp, device=dev, dtype=dt)
+        act = {"gelu_tanh": L.ACT_GELU_TANH, "gelu_erf": L.ACT_GELU_ERF, "swiglu": L.ACT_SWIGLU}[t.act]
+        mlp = torch.empty(B * S, t.layers[0].fc2.w.shape[1], device=dev, dtype=dt)
+        scale = t.head_dim ** -0.5
+        for Lr in t.layers:
+            ops.layernorm(x16, Lr.ln1_g, Lr.ln1_b, t.eps, D, dt, y16=h16, x16_kernel=True)
+            ops.gemm(h16, Lr.qkv.w, Lr.qkv.b, out=qkv)
+            ld = qkv.stride(0)
+            ops.attention(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], attn, B, t.heads, t.head_dim, S, S, scale,
+                          S * ld, S * ld, S * ld, S * attn.stride(0))
+            ops.gemm(attn, Lr.out.w, Lr.out.b, res=x16, out=x16)
+            ops.layernorm(x16, Lr.ln2_g, Lr.ln2_b, t.eps, D, dt, y16=h16, x16_kernel=True)
+            ops.gemm(h16, Lr.fc1.w, Lr.fc1.b, act=act, out=mlp)
+            ops.gemm(mlp, Lr.fc2.w, Lr.fc2.b, res=x16, out=x16)
+        src, sdt = x16, rd
+        if t.get("final_ln"):
+            ops.layernorm(x16, t.final_ln[0], t.final_ln[1], t.eps, D, dt, y16=h16, x16_kernel=True)
+            src, sdt = h16, dt
+        return ops.resample_tokens(src, B, t.has_cls, gh, out_grid, D, sdt, self._bil(gh, out_grid), out_dtype=self.dtype)
 
     # ------------------------------------------------------------------------------------------------ a5
     def sims_tensor(self, dino_feat, T):
@@ -435,7 +485,7 @@ class VideoEncoder:
         return out
 
     def connector(self, sig_feat, dino_feat, T, image_sizes, keep=None):
-        if keep is None and getattr(self, "native_connector", True) and ops.PROFILE is None:
+        if keep is None and getattr(self, "native_connector", True):
             feat = self._connector_native(sig_feat, dino_feat, T, image_sizes)
             return self.unpad_newline(feat, T, image_sizes)
         aux = [self.aux_project(sig_feat, 0), self.aux_project(dino_feat, 1)]
@@ -466,14 +516,14 @@ class VideoEncoder:
         out_fused = not fused and mode >= 1 and ops.qformer_xattn_supported(Dq, heads, K, 8)
         if fused or out_fused:
             self._tile_cross_weights()
-        ops.TAG = "xattn_block"
+        ops.profile_tag(L.PROF_TAG_XATTN_BLOCK)
         if fused:
             k_all = ops.gemm(enc, qf.cross_k.w, qf.cross_k.b, M=F * Nenc)     # [F*Nenc, n_cross*Dq]
-            vt_all = torch.empty(qf.cross_v.w.shape[0], pad64(F * Nenc), device=self.dev, dtype=dt)
+            vt_all = torch.empty(qf.cross_v.w.shape[0], pad64(F * Nenc + 4), device=self.dev, dtype=dt)   # ldvt >= round_up(F*Nenc, 8)
             ops.gemm(qf.cross_v.w, enc[:F * Nenc], out=vt_all, c_pad8=True)   # V^T = Wv enc^T: [n_cross*Dq, F*Nenc]
         else:
             kv_all = ops.gemm(enc, qf.cross_kv.w, qf.cross_kv.b)              # [F*Nenc, n_cross*2*Dq]
-        ops.TAG = None
+        ops.profile_tag(0)
         Dp = h16.shape[1]
         ctx = torch.zeros(F * S, Dp, device=self.dev, dtype=dt)
         ctx_q = torch.zeros(F * K, Dp, device=self.dev, dtype=dt)
@@ -490,7 +540,7 @@ class VideoEncoder:
                           S * ld, S * ld, S * ld, S * ctx.stride(0))
             ops.gemm(ctx, Lr.attn_out.w, Lr.attn_out.b, res=h32, out=t32, out_f32=True)
             ops.layernorm(t32, Lr.attn_ln[0], Lr.attn_ln[1], 1e-12, Dq, dt, y16=h16, y32=h32)
-            ops.TAG = "xattn_block"
+            ops.profile_tag(L.PROF_TAG_XATTN_BLOCK)
             if Lr.cross is not None and fused:
                 j = Lr.cross.idx
                 ops.qformer_xattn(h16, h32, F, K, S, Lr.cross.q_tiled, Lr.cross.q.b, Lr.cross.out_tiled, Lr.cross.out.b,
@@ -515,7 +565,7 @@ class VideoEncoder:
                     ops.gemm(ctx_q, Lr.cross.out.w, Lr.cross.out.b, res=h32, r_map=qmap, out=t32, out_f32=True, M=F * K)
                     ops.layernorm(t32, Lr.cross.ln[0], Lr.cross.ln[1], 1e-12, Dq, dt, y16=h16, y32=h32, rows=F * K,
                                   y_map=qmap)
-            ops.TAG = None
+            ops.profile_tag(0)
             m = ops.gemm(h16, Lr.ffn_q.fc1.w, Lr.ffn_q.fc1.b, act=L.ACT_GELU_ERF, M=F * K, a_map=qmap)
             if q16:
                 ops.gemm(m, Lr.ffn_q.fc2.w, Lr.ffn_q.fc2.b, res=h16, r_map=qmap, out=t16, M=F * K)
@@ -726,7 +776,7 @@ class VideoEncoder:
         enc_idx[:, 1] = (fr[:, None] * Nf + torch.arange(Nf, dtype=torch.int32, device=dev)[None, :]).reshape(-1)
         enc = ops.gather_rows([Xf], enc_idx, F * Nf, Hp, validated=True)      # frame_rows range-checked above
         qs = torch.tensor(qsrc, dtype=torch.int32, device=dev)
-        if getattr(self, "native_qformer", True) and ops.PROFILE is None:
+        if getattr(self, "native_qformer", True):
             comp = self._compress_native(enc, F, Nf, qtable, qs, prompt_ids)
             if keep is not None:
                 keep.update(compressed=comp)

@@ -19,6 +19,12 @@ def pad64(n):
     return (n + 63) // 64 * 64
 
 
+def _register_real_nk(w, n, k):
+    """un-padded dims of a prepared weight: kept on the tensor and, by data pointer, for the library's launch profiler"""
+    from . import ops
+    ops.register_real_nk(w, n, k)
+
+
 class Lin:
     """Prepared nn.Linear: w [n_pad, k_pad] 16-bit, b fp32 [n_pad] or None."""
     __slots__ = ("w", "b", "n", "k", "wscale", "zeros", "w2max", "bmax")
@@ -56,7 +62,7 @@ def make_lin(W, b, dtype, dev, row_scale=None, col_scale=None, col_shift=None, n
         bp[:n] = bias
         bp = bp.to(dev)
     w = Wp.to(dev).contiguous()
-    w._real_nk = (n, k)  # algorithmic dims for FLOP accounting (bench.py)
+    _register_real_nk(w, n, k)  # algorithmic dims for FLOP accounting (bench.py)
     return Lin(w, bp, n, k)
 
 
@@ -89,7 +95,7 @@ def to_fp8(lin, dev):
     w2max = float(Wq.float().norm(dim=1).max())
     bmax = float(lin.b.abs().max()) if lin.b is not None else 0.0
     W8 = W8.to(dev).contiguous()
-    W8._real_nk = getattr(lin.w, "_real_nk", (lin.n, lin.k))
+    _register_real_nk(W8, *getattr(lin.w, "_real_nk", (lin.n, lin.k)))
     return Lin(W8, lin.b, lin.n, lin.k, wscale=sw, zeros=torch.zeros(n_pad, dtype=torch.float32, device=dev),
                w2max=w2max, bmax=bmax)
 
@@ -247,7 +253,7 @@ def prep_dino(sd, heads, dtype, dev, patch=14, eps=1e-6, fp8=False, ln_fuse=Fals
             Wi[0:2 * hid:2], Wi[1:2 * hid:2] = Win[:hid], Win[hid:]
             bi[0:2 * hid:2], bi[1:2 * hid:2] = bin_[:hid], bin_[hid:]
             Lr.fc1 = make_lin(Wi, bi, dtype, dev, n_pad=2 * hp, **f2)
-            Lr.fc1.w._real_nk = (2 * hid, Win.shape[1])
+            _register_real_nk(Lr.fc1.w, 2 * hid, Win.shape[1])
             Lr.fc2 = make_lin(sd[p + "mlp.weights_out.weight"], sd[p + "mlp.weights_out.bias"], dtype, dev,
                               row_scale=sd[p + "layer_scale2.lambda1"])
             t.act = "swiglu"

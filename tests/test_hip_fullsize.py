@@ -258,6 +258,59 @@ def test_fullsize_video_plus_audio_token_accounting(full):
             enc.cfg.pop("audio_input", None)
 
 
+def test_config4_T512_with_512s_of_audio_properties():
+    """BASELINE config 4 at ITS OWN size, in the bench's type (bf16 tower operands, fp16 residual stream, fp16 connector /
+    Q-Former): one 512-frame video + 512 s of 16 kHz audio through BEATs (released dimensions), 50 audio tokens per frame in
+    the Q-Former KV (N = 206).  The oracle cannot run this size; checked are the size-independent properties: token accounting
+    (SURVEY appendix B with the audio rows), bitwise run-to-run determinism, bitwise tower-batch invariance (512 frames in
+    one batch == batches of 96 with a ragged tail), unit-norm compressed rows, verbatim separators."""
+    import bench
+    import tdc_video_amd  # noqa: F401
+    from tdc_video_amd import weights as Wt
+    from tdc_video_amd.beats import BEATS_ITER3_CFG, BeatsEncoder
+    from tdc_video_amd.pipeline import VideoEncoder
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_beats import random_beats_state
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(0)
+    H, K, T, N = 3584, 144, 512, 156
+    sd = bench.random_state_dict(H, K, dev, gen)
+    enc = VideoEncoder(sd, bench.model_cfg(H, K, T), dtype=torch.float16, tower_dtype=torch.bfloat16, device=dev,
+                       tower_batch=512, tower_res_dtype=torch.float16)
+    del sd
+    enc.cfg["audio_input"] = True
+    enc.c.audio_proj = Wt.make_lin(torch.randn(H, 768, device=dev, generator=gen) * 0.02, torch.zeros(H, device=dev),
+                                   torch.float16, dev)
+    enc.beats = BeatsEncoder(random_beats_state(BEATS_ITER3_CFG), BEATS_ITER3_CFG, dtype=torch.float16, device=dev)
+    torch.cuda.empty_cache()
+    wav = (0.1 * torch.randn(1, 16000 * T, device=dev, generator=gen)).half()
+    vs = bench.synth_video(0, T, 384, dev, torch.bfloat16)
+    vd = bench.synth_video(0, T, 378, dev, torch.bfloat16, seed=4321)
+    prompt = [101] + list(range(2000, 2010)) + [102]
+
+    def go(keep=None):
+        return enc.encode_video(vs, vd, (384, 384), budget_text_len=64, n_text_tokens=64, prompt_ids=prompt, frame_cap=T,
+                                audio={"audio_wav": wav}, keep=keep)
+    keep = {}
+    a = go(keep)
+    b = go()
+    assert torch.equal(a, b)                                            # run to run
+    enc.tower_batch = 96                                                # 5 batches of 96 + a ragged tail of 32
+    c = go()
+    assert torch.equal(a, c)                                            # tower-batch invariance
+    plan = keep["plan"]
+    n_static, n_comp = len(plan["chunks"]), len(plan["comp_frames"])
+    assert len(keep["selected"]) == T and n_static + n_comp == T and n_comp > 0
+    assert a.shape[0] == n_static * (N + 50 + 1) + n_comp * (K + 1) and torch.isfinite(a.float()).all()
+    rows = a.float()
+    comp = torch.from_numpy((plan.kind == 1).nonzero()[0]).to(dev)
+    assert comp.numel() == n_comp * K
+    assert (rows[comp].norm(dim=1) - 1).abs().max().item() < 2e-3       # unit-norm compressed context rows (fp16 storage)
+    seps = torch.from_numpy((plan.kind == 2).nonzero()[0]).to(dev)
+    assert seps.numel() == T
+    assert torch.equal(a[seps], enc.c.frame_seg[0, :H].to(a.dtype).expand(seps.numel(), H))
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 8e-3), (torch.bfloat16, 6e-2)])
 def test_fullsize_ln_fusion_matches_layernorm_kernel(full_sd, dtype, tol, monkeypatch):
     """VideoEncoder(ln_fuse=True) (pre-LayerNorms folded into the neighbouring GEMMs: 16-bit row copy + per-slot statistics out of the

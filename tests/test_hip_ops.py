@@ -595,3 +595,93 @@ def test_qformer_xattn_output_projection_only(ops, dtype, F, K, Lt):
     y16 = torch.nn.functional.layer_norm(ctx.float() @ wo.float().t() + bo + ref16[rows].float(), (D,), ln_g, ln_b, 1e-12)
     assert (h16b[rows].float() - y16).abs().max().item() < (4e-3 if dtype == torch.float16 else 3e-2)
     assert torch.equal(h16b[other], ref16[other])
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cdtype", DT)
+@pytest.mark.parametrize("M", [300, 40 * 256 + 7, 80 * 256 - 19])    # 128x128, 256x256 and persistent kernels
+def test_gemm_16bit_residual_read_modify_write(ops, dtype, cdtype, M):
+    """C = T16(acc + bias + float(res)) with ONE rounding - the update of a 16-bit residual stream (tdc_vit_model.res_dtype_p1) -
+    for both 16-bit types of C / res under both operand types (tdc_gemm_desc.c16_dtype_p1), in place and out of place, ragged
+    M / N edges, row maps; bitwise independent of the kernel that computes a row."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    N, K = 1160, 192
+    a = torch.randn(M, K, device="cuda", generator=g).to(dtype)
+    w = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).to(dtype)
+    bias = torch.randn(N, device="cuda", generator=g)
+    res = (3 * torch.randn(M, N, device="cuda", generator=g)).to(cdtype)
+    ref = (a.float() @ w.float().t() + bias + res.float())
+    out = torch.empty(M, N, device="cuda", dtype=cdtype)
+    ops.gemm(a, w, bias, res=res, out=out)
+    assert out.dtype == cdtype
+    # one rounding of an fp32 sum: within 1 ulp of the rounded reference (the fp32 accumulation order differs from torch's)
+    ulp = 2.0 ** -10 if cdtype == torch.float16 else 2.0 ** -7
+    assert ((out.float() - ref).abs() / ref.abs().clamp_min(1.0)).max().item() < 1.1 * ulp
+    r2 = res.clone()
+    ops.gemm(a, w, bias, res=r2, out=r2)                       # in place
+    assert torch.equal(r2, out)
+    for lo in (0, M // 2 + 5, M - 260):
+        if lo < 0:
+            continue
+        n = min(260, M - lo)
+        sub = torch.empty(n, N, device="cuda", dtype=cdtype)
+        ops.gemm(a[lo:lo + n].contiguous(), w, bias, res=res[lo:lo + n].contiguous(), out=sub)
+        assert torch.equal(sub, out[lo:lo + n])
+    # fp32 residual (a position table through a row map) into a 16-bit stream of the other type: the patch-embed GEMM
+    P, S, B = 50, 51, M // 50
+    if B >= 1:
+        pos = torch.randn(S, N, device="cuda", generator=g)
+        x = torch.zeros(B * S, N, device="cuda", dtype=cdtype)
+        ops.gemm(a[:B * P].contiguous(), w, bias, res=pos, r_map=(P, 0, 1, 1), out=x, c_map=(P, S, 1, 1))
+        refp = (a[:B * P].float() @ w.float().t() + bias).view(B, P, N) + pos[1:][None]
+        got = x.view(B, S, N)
+        assert ((got[:, 1:].float() - refp).abs() / refp.abs().clamp_min(1.0)).max().item() < 1.1 * ulp
+        assert torch.count_nonzero(got[:, 0]) == 0
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("xdtype", DT)
+@pytest.mark.parametrize("cols", [768, 1152, 1536])
+def test_layernorm_16bit_rows_in_16bit_rows_out(ops, dtype, xdtype, cols):
+    """the towers' LayerNorm over a 16-bit residual stream (tdc_ln_desc.x_dtype_p1): 16-byte accesses, input / output types free"""
+    g = torch.Generator(device="cuda").manual_seed(4)
+    rows, ld = 531, ops.pad64(cols)
+    x = torch.zeros(rows, ld, device="cuda")
+    x[:, :cols] = torch.randn(rows, cols, device="cuda", generator=g) * 3 + 1
+    x16 = x.to(xdtype)
+    gamma = torch.randn(cols, device="cuda", generator=g)
+    beta = torch.randn(cols, device="cuda", generator=g)
+    y = torch.full((rows, ld), 7.0, device="cuda", dtype=dtype)
+    ops.layernorm(x16, gamma, beta, 1e-6, cols, dtype, y16=y, x16_kernel=True)
+    ref = F.layer_norm(x16[:, :cols].float(), (cols,), gamma, beta, 1e-6)
+    assert relerr(y[:, :cols], ref) < tol(dtype)
+    assert torch.count_nonzero(y[:, cols:]) == 0
+    # the same rows through the general kernel (same-type input only): equal up to the rounding of the output
+    if xdtype == dtype:
+        y2, _ = ops.layernorm(x16, gamma, beta, 1e-6, cols, dtype)
+        assert relerr(y2[:, :cols], y[:, :cols]) < tol(dtype)
+
+
+def test_set_rows16_and_launch_profiler(ops):
+    from tdc_video_amd import lib as L
+    x = torch.zeros(3 * 5, 64, device="cuda", dtype=torch.float16)
+    vec = torch.arange(64, device="cuda", dtype=torch.float32) / 8
+    ops.set_rows16(x, 3, 5, 2, vec)
+    assert torch.equal(x.view(3, 5, 64)[:, 2], vec.half().expand(3, 64)) and torch.count_nonzero(x.view(3, 5, 64)[:, :2]) == 0
+    # the profiler sees direct calls and calls made inside a composite alike, in launch order, with their shapes
+    g = torch.Generator(device="cuda").manual_seed(0)
+    a = torch.randn(300, 128, device="cuda", generator=g).half()
+    w = torch.randn(192, 128, device="cuda", generator=g).half()
+    ops.profile_start(64)
+    ops.gemm(a, w)
+    ops.profile_tag(L.PROF_TAG_XATTN_BLOCK)
+    ops.layernorm(a, torch.ones(128, device="cuda"), torch.zeros(128, device="cuda"), 1e-6, 128, torch.float16)
+    ops.profile_tag(0)
+    ops.gemm(a, w, out_f32=True)
+    recs = ops.profile_stop(64)
+    assert [r["kind"] for r in recs] == ["gemm", "ln", "gemm"] and [r["tag"] for r in recs] == [0, 1, 0]
+    assert (recs[0]["M"], recs[0]["N"], recs[0]["K"], recs[0]["out_f32"]) == (300, 192, 128, 0) and recs[2]["out_f32"] == 1
+    assert recs[0]["flops"] == 2.0 * 300 * 192 * 128 and all(r["ms"] > 0 for r in recs)
+    ops.gemm(a, w)                     # off again: nothing is recorded, a second profile starts empty
+    ops.profile_start(8)
+    assert ops.profile_stop(8) == []

@@ -25,26 +25,31 @@ def rel(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item()
 
 
-MIXED = "bf16 towers + fp16"     # the bench's type: towers in bf16, connector / Q-Former in fp16 (VideoEncoder.tower_dtype)
+MIXED = "bf16 towers + fp16"     # rounds 2-3 bench type: towers in bf16 (fp32 residual stream), connector / Q-Former in fp16
+MIXED_R16 = "bf16 towers, fp16 residual stream + fp16"    # the bench's type: as MIXED with the towers' residual stream in fp16
+F16_R16 = "fp16, fp16 residual stream"                    # the reference's own arithmetic (torch_dtype=float16 end to end)
 
 
 def stage_tol(dtype, key=""):
     """max|err| / max|ref| of a stage output, every fixture and stage alike (measured: fp16 <= 1.1e-3, bf16 <= 8e-3).  The
     mixed type inherits the bf16 towers' error in every stage behind them."""
-    return 4e-3 if dtype == torch.float16 else 3e-2
+    return 4e-3 if dtype in (torch.float16, F16_R16) else 3e-2
 
 
 def comp_tol(dtype):
-    """compressed (unit-norm) context tokens, absolute: the north_star's 1e-3 for fp16 AND for the bench's mixed type"""
+    """compressed (unit-norm) context tokens, absolute: the north_star's 1e-3 for fp16 AND for the bench's mixed types"""
     return 8e-3 if dtype == torch.bfloat16 else 1e-3
 
 
 def make_encoder(W, cfg, dtype):
     import tdc_video_amd  # noqa: F401
     from tdc_video_amd.pipeline import VideoEncoder
-    if dtype == MIXED:
+    if dtype in (MIXED, MIXED_R16):
         return VideoEncoder(W, cfg, dtype=torch.float16, tower_dtype=torch.bfloat16, device="cuda", siglip_heads=4,
-                            dino_heads=4, qformer_heads=4)
+                            dino_heads=4, qformer_heads=4, tower_res_dtype=torch.float16 if dtype == MIXED_R16 else None)
+    if dtype == F16_R16:
+        return VideoEncoder(W, cfg, dtype=torch.float16, device="cuda", siglip_heads=4, dino_heads=4, qformer_heads=4,
+                            tower_res_dtype=torch.float16)
     return VideoEncoder(W, cfg, dtype=dtype, device="cuda", siglip_heads=4, dino_heads=4, qformer_heads=4)
 
 
@@ -224,7 +229,7 @@ def test_qformer_chunk_vs_golden(dtype):
     assert torch.equal(vis[N + 1:N + 1 + K].cpu(), keep["compressed"][:K, :H].cpu())
 
 
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, MIXED])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, MIXED, MIXED_R16, F16_R16])
 @pytest.mark.parametrize("name", ["pipeline_T40.npz", "pipeline_T10_land.npz", "pipeline_T260.npz"])
 def test_full_pipeline_vs_golden(name, dtype):
     W, o = load_fixture(name)
@@ -278,7 +283,7 @@ def test_full_pipeline_vs_golden(name, dtype):
         assert err < comp_tol(dtype), err
 
 
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, MIXED])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, MIXED, MIXED_R16])
 @pytest.mark.parametrize("name", ["pipeline_T40_nostatic.npz", "pipeline_T40_learned.npz"])
 def test_config_ablations_vs_golden(name, dtype):
     """add_static=False / query_type='learned' (reference-generated fixtures): emitted stream vs the reference's."""
@@ -493,6 +498,37 @@ def test_native_tower_composite_equals_kernel_sequence(dtype, fuse, monkeypatch)
         enc.native_towers = False
         b = enc.tower(prep, px)
         assert torch.equal(a, b), name
+
+
+@pytest.mark.parametrize("dtype,rdtype", [(torch.float16, torch.float16), (torch.bfloat16, torch.float16),
+                                          (torch.bfloat16, torch.bfloat16), (torch.float16, torch.bfloat16)])
+def test_towers_16bit_residual_stream(dtype, rdtype):
+    """The towers over a 16-bit residual stream (tdc_vit_model.res_dtype_p1): tdc_vit_fwd == the per-kernel sequence bit for bit,
+    features within the stage tolerance of the reference-generated fixtures (bf16 streams: the bf16 bound), pad columns zero."""
+    import tdc_video_amd  # noqa: F401
+    from tdc_video_amd import weights as Wt
+    from tdc_video_amd.pipeline import VideoEncoder
+    for name, prep in (("siglip_small.npz", "siglip"), ("dino_small.npz", "dino")):
+        W, o = load_fixture(name)
+        enc = VideoEncoder.__new__(VideoEncoder)
+        enc.dtype, enc.dev, enc.tower_batch = dtype, torch.device("cuda"), 2
+        enc.tower_res_dtype = rdtype
+        enc._tables = {}
+        enc.out_grid = [8, 8]
+        t = (Wt.prep_siglip if prep == "siglip" else Wt.prep_dino)(W, 4, dtype, enc.dev)
+        enc.towers = {prep: t}
+        px = torch.from_numpy(o["pixels"]).cuda()
+        enc.native_towers = True
+        a = enc.tower(prep, px)
+        enc.native_towers = False
+        b = enc.tower(prep, px)
+        assert torch.equal(a, b), name
+        got = a[:, :t.dim].reshape(px.shape[0], 64, t.dim)
+        bound = stage_tol(torch.bfloat16 if torch.bfloat16 in (dtype, rdtype) else torch.float16)
+        err = rel(got, o["out"])
+        print("%s towers %s residual %s: %.3e of max|ref|" % (name, dtype, rdtype, err))
+        assert err < bound, (name, err)
+        assert torch.count_nonzero(a[:, t.dim:]) == 0
 
 
 def test_tower_drops_trailing_pixels_like_valid_conv():
