@@ -224,7 +224,7 @@ class ShardedVideoEncoder:
         # workgroups (T = 64 on one GPU: +0.6-1.1 %; at 512 frames per launch the tails are too short to matter)
         side, sig_early = None, None
         if getattr(e, "two_streams", False) and px_siglip_local.is_cuda:
-            side = torch.cuda.Stream(device=px_siglip_local.device)
+            side = e.tower_stream() if hasattr(e, "tower_stream") else torch.cuda.Stream(device=px_siglip_local.device)
             side.wait_stream(torch.cuda.current_stream(px_siglip_local.device))
             with torch.cuda.stream(side):
                 sig_early = e.tower("siglip", px_siglip_local)

@@ -152,7 +152,8 @@ def gemm(a, w, bias=None, act=L.ACT_NONE, res=None, out=None, out_f32=False, M=N
         d.res, d.ldres = res.data_ptr(), res.stride(0)
         d.res_f32 = 1 if res.dtype == torch.float32 else 0
         if not d.res_f32:
-            assert res.dtype == out.dtype, "a 16-bit residual has the type of the 16-bit output"
+            assert res.dtype == (a.dtype if (out_f32 or fp8) else out.dtype), \
+                "a 16-bit residual has the type of the 16-bit output (of the operands when the output is fp32)"
     d.M, d.N, d.K = M, N, K
     d.dtype, d.out_f32, d.act = _dtcode(out_dtype), int(out_f32), act
     d.in_fp8 = int(fp8)

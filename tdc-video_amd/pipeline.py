@@ -325,6 +325,14 @@ class VideoEncoder:
         ev.record(torch.cuda.current_stream(self.dev))
         return ev
 
+    def tower_stream(self):
+        """the ONE side stream the SigLIP tower runs on under `two_streams` (kept for the engine's life: its per-tower workspace
+        `_vit_ws_siglip` and the cached tables are allocated under it once and never migrate between pool streams)"""
+        st = self.__dict__.get("_tower_stream")
+        if st is None:
+            st = self._tower_stream = torch.cuda.Stream(device=self.dev)
+        return st
+
     def after(self, ev):
         side = self.__dict__.get("_side_stream")
         if side is None:
@@ -895,7 +903,7 @@ def encode_video_with(e, px_siglip, px_dino, image_size, budget_text_len, n_text
     # filled by the other tower's workgroups.
     side = None
     if getattr(e, "two_streams", False) and T <= frame_cap and px_siglip.is_cuda:
-        side = torch.cuda.Stream(device=px_siglip.device)
+        side = e.tower_stream() if hasattr(e, "tower_stream") else torch.cuda.Stream(device=px_siglip.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             sig_early = e.tower("siglip", px_siglip)

@@ -155,7 +155,10 @@ def test_config1_full_depth_end_to_end_vs_oracle(tower_dtype, res_dtype, px):
     enc = VideoEncoder(sd, cfg, dtype=torch.float16, tower_dtype=tower_dtype, device="cuda:0", siglip_heads=16, dino_heads=24,
                        qformer_heads=12, tower_res_dtype=res_dtype)
     assert len(enc.towers["siglip"].layers) == 27 and len(enc.towers["dino"].layers) == 40
-    tol_tower = 4e-3 if tower_dtype == torch.float16 else 6e-2
+    # raw tower features, of max|ref|: fp16 operands 4e-3 over an fp32 residual stream (measured 9.5e-4 / 2.5e-3), 8e-3 over an fp16
+    # one (2.8e-3 / 4.2e-3: 80 residual adds rounded to 11 bits each - the reference's own fp16 arithmetic; the bound of
+    # test_config2's full-depth towers); bf16 operands 6e-2 either way (6.5e-3 / 2.1e-2)
+    tol_tower = 6e-2 if tower_dtype == torch.bfloat16 else 8e-3 if res_dtype is not None else 4e-3
     keep = {}
     got = enc.encode_video(vs, vd, (px, px), budget_text_len=ids.shape[1], n_text_tokens=ids.shape[1] - 1,
                            prompt_ids=PROMPT, keep=keep)
