@@ -48,12 +48,25 @@ __device__ __forceinline__ void both_halves(float v, float& lo, float& hi) {
     hi = __builtin_bit_cast(float, (unsigned)sw[1]);
 }
 
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E) - every index inside is a constant expression, so the
+// register arrays below are never addressed at run time (a run-time index sends them to scratch)
+template <int B, int E>
+struct StaticFor {
+    template <class F>
+    static __device__ __forceinline__ void run(F&& f) {
+        if constexpr (B < E) {
+            f(std::integral_constant<int, B>());
+            StaticFor<B + 1, E>::run(f);
+        }
+    }
+};
+
 constexpr int PW_KT = 64;           // keys per tile
 constexpr int PW_RING = 4;          // ring slots per operand
 constexpr int PW_TILE_BYTES = 8192; // 64 keys x 128 B (head dim 64)
 
 // head dim 64: DK = 64 (4 k-steps), 2 output blocks of 32 columns; a wave = 2 query blocks of 32 rows
-template <class T>
+template <class T, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void attn_pw64_kernel(AttnArgs p) {
     typedef typename VecOf<T>::v8 v8;
     typedef typename VecOf<T>::v4 v4;
@@ -93,34 +106,40 @@ __global__ __launch_bounds__(256, 1) void attn_pw64_kernel(AttnArgs p) {
     //      lane -> row 8 pi + (lane >> 3), physical 16-B chunk lane & 7; the source chunk is the swizzle's inverse image:
     //      K: chunk ^ ((key >> 1) & 7)   (ds_read_b128 of 16-lane groups conflict-free), V: chunk ^ (((key >> 1) & 1) << 2)
     //      (the four keys of a transposed read fall on four 64-byte bank groups) - the images attention32.hip reads.
+    // Addresses = a wave-uniform tile base (SGPR pair, advanced by 64 rows per tile) + a per-lane 32-bit offset computed once: the
+    // DMA then issues in the `saddr` form and no 64-bit address arithmetic sits in the loop.  The last tile's rows >= sk are
+    // clamped to row sk - 1 through a second offset set; requests past the last tile (the ring runs ahead) repeat the last tile.
     const int srow = lane >> 3, sch = lane & 7;
-    int krow_[2], kcb[2], vcb[2];
+    const int ntiles = (p.sk + PW_KT - 1) / PW_KT;
+    const int last_rows = p.sk - (ntiles - 1) * PW_KT;          // 1..64 valid rows in the last tile
+    unsigned koff[2], voff[2], koff_l[2], voff_l[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int key = (wave * 2 + j) * 8 + srow;
-        krow_[j] = key;
-        kcb[j] = (sch ^ ((key >> 1) & 7)) * 16;
-        vcb[j] = (sch ^ (((key >> 1) & 1) << 2)) * 16;
+        const int keyc = key < last_rows ? key : last_rows - 1;
+        const unsigned kc = (unsigned)(sch ^ ((key >> 1) & 7)) * 16u, vc = (unsigned)(sch ^ (((key >> 1) & 1) << 2)) * 16u;
+        koff[j] = (unsigned)key * (unsigned)p.k_rs * 2u + kc;
+        voff[j] = (unsigned)key * (unsigned)p.v_rs * 2u + vc;
+        koff_l[j] = (unsigned)keyc * (unsigned)p.k_rs * 2u + kc;
+        voff_l[j] = (unsigned)keyc * (unsigned)p.v_rs * 2u + vc;
     }
-    const long long k_rsb = (long long)p.k_rs * 2, v_rsb = (long long)p.v_rs * 2;
-    auto dma_k = [&](int tile) {
-        char* kd = Kr + (tile & (PW_RING - 1)) * PW_TILE_BYTES + wave * 2048;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            int kr = tile * PW_KT + krow_[j];
-            if (kr > p.sk - 1) kr = p.sk - 1;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(K + kr * k_rsb + kcb[j]), LDS_PTR(kd + j * 1024), 16, 0, 0);
-        }
+    const long long k_tile = (long long)p.k_rs * 2 * PW_KT, v_tile = (long long)p.v_rs * 2 * PW_KT;
+    auto dma_k_piece = [&](int tile, int j) {
+        const int tb = tile < ntiles - 1 ? tile : ntiles - 1;
+        const char* base = K + tb * k_tile;                                   // wave-uniform
+        const unsigned off = tile < ntiles - 1 ? koff[j] : koff_l[j];
+        char* kd = Kr + (tile & (PW_RING - 1)) * PW_TILE_BYTES + wave * 2048 + j * 1024;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(base + off), LDS_PTR(kd), 16, 0, 0);
     };
-    auto dma_v = [&](int tile) {
-        char* vd = Vr + (tile & (PW_RING - 1)) * PW_TILE_BYTES + wave * 2048;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            int kr = tile * PW_KT + krow_[j];
-            if (kr > p.sk - 1) kr = p.sk - 1;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(V + kr * v_rsb + vcb[j]), LDS_PTR(vd + j * 1024), 16, 0, 0);
-        }
+    auto dma_v_piece = [&](int tile, int j) {
+        const int tb = tile < ntiles - 1 ? tile : ntiles - 1;
+        const char* base = V + tb * v_tile;
+        const unsigned off = tile < ntiles - 1 ? voff[j] : voff_l[j];
+        char* vd = Vr + (tile & (PW_RING - 1)) * PW_TILE_BYTES + wave * 2048 + j * 1024;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(base + off), LDS_PTR(vd), 16, 0, 0);
     };
+    auto dma_k = [&](int tile) { dma_k_piece(tile, 0); dma_k_piece(tile, 1); };
+    auto dma_v = [&](int tile) { dma_v_piece(tile, 0); dma_v_piece(tile, 1); };
 
     // ---- fragment read offsets (bytes inside a tile image)
     int k_off[2][KS];         // A operand of QK^T: key 32 kb + r, logical chunk 2 ks + hh
@@ -164,6 +183,11 @@ __global__ __launch_bounds__(256, 1) void attn_pw64_kernel(AttnArgs p) {
         else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "a"(b));
     };
     auto mfma_o = [&](f32x16& acc, const v8& a, const v8& b) {       // acc += a b   (O in AGPRs, P from VGPRs)
+        if constexpr (!(DBG & 128)) { acc = mfma32(a, b, acc); return; }
+        // (needed for correctness with hipcc 7.2: without this empty statement that re-defines the accumulator in front of every
+        // MFMA, the first register of each O tuple loses what the loop accumulated - the O rescale's element-wise code and the asm
+        // MFMAs' tied 512-bit AGPR operands do not mix; found with tools/debug_attn_pw.py, kept under test_attention_pw_form)
+        asm volatile("" : "+a"(acc));
         if constexpr (std::is_same<T, f16>::value) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
         else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
     };
@@ -179,7 +203,6 @@ __global__ __launch_bounds__(256, 1) void attn_pw64_kernel(AttnArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) o_acc[qb][db][e] = 0.f;
     }
-    const int ntiles = (p.sk + PW_KT - 1) / PW_KT;
     const float c = p.scale_log2;
 
 #define PW_SYNC(N)                                                       \
@@ -221,6 +244,18 @@ __global__ __launch_bounds__(256, 1) void attn_pw64_kernel(AttnArgs p) {
         asm volatile("s_nop 15\n\ts_nop 15" : "+v"(sA[0][0]), "+v"(sA[0][1]), "+v"(sA[1][0]), "+v"(sA[1][1]));
     }
 
+    // in-kernel cycle stamps of the timing build (DBG & 0x2000; tools/debug_attn_pw.py): cycles spent, summed over the
+    // iterations, in the sync, slots 0-7, 8-15, 16-23, 24-31 and the tail of an iteration
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = 0;
+    auto stamp = [&](int k) {
+        if constexpr (DBG & 0x2000) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            if (k >= 0) st_acc[k] += now - st_prev;
+            st_prev = now;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     // iteration t: [barrier: K(<= t+2), V(<= t) landed] DMA K(t+4), V(t+2), then 32 slots of {one MFMA, a slice of the softmax,
     // a fragment read}: MFMAs 0-15 = S(t+1) = K(t+1) Q^T, 16-31 = O += V(t-1)^T P(t-1); VALU = P(t) = softmax(S(t)); LDS = the
     // K(t+2) / V(t) fragments, each register set re-read right behind the two MFMAs that used it.  The order is pinned
@@ -228,10 +263,10 @@ __global__ __launch_bounds__(256, 1) void attn_pw64_kernel(AttnArgs p) {
     auto iter = [&](int t, f32x16 (&s_cur)[QB][2], f32x16 (&s_nxt)[QB][2], v8 (&p_cur)[QB][2][2], v8 (&p_prv)[QB][2][2],
                     auto qk_c, auto pv_c, auto partial_c) {
         constexpr bool HAS_QK = decltype(qk_c)::value, HAS_PV = decltype(pv_c)::value, PARTIAL = decltype(partial_c)::value;
-        PW_SYNC(4);
-        dma_k(t + 4);
-        dma_v(t + 2);
+        stamp(-1);
+        if constexpr (!(DBG & 0x800)) { PW_SYNC(4); }
         PW_PIN();
+        stamp(0);
         const char* kbase = Kr + ((t + 2) & (PW_RING - 1)) * PW_TILE_BYTES;
         const unsigned vbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)Vr + (t & (PW_RING - 1)) * PW_TILE_BYTES;
         const int kv0 = t * PW_KT;
@@ -244,22 +279,32 @@ __global__ __launch_bounds__(256, 1) void attn_pw64_kernel(AttnArgs p) {
                     for (int e = 0; e < 16; ++e)
                         if (kv0 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh >= p.sk) s_cur[qb][kb][e] = -INFINITY;
         }
-        float mx[QB], nm[QB], alpha[QB], rs0[QB], rs1[QB];
-        // softmax slices.  max_part(qb, part): running maximum over 8 of the row's 32 scores; max_fin(qb): both lane halves, the
-        // new running maximum, the scale of the older sums; pair(qb, i): scores 2 i, 2 i + 1 of the row -> two exponentials,
-        // their row-sum terms and one packed conversion (i = 16 kb + 8 st + j / 2 in the PV product's contraction order)
-        auto max_part = [&](int qb, int part) {
-            const int kb = part >> 1, e0 = (part & 1) * 8;
-            float m = __builtin_fmaxf(__builtin_fmaxf(s_cur[qb][kb][e0], s_cur[qb][kb][e0 + 1]), s_cur[qb][kb][e0 + 2]);
-            m = __builtin_fmaxf(__builtin_fmaxf(m, s_cur[qb][kb][e0 + 3]), s_cur[qb][kb][e0 + 4]);
-            m = __builtin_fmaxf(__builtin_fmaxf(m, s_cur[qb][kb][e0 + 5]), s_cur[qb][kb][e0 + 6]);
-            m = __builtin_fmaxf(m, s_cur[qb][kb][e0 + 7]);
-            mx[qb] = part == 0 ? m : __builtin_fmaxf(mx[qb], m);
-            asm volatile("" : "+v"(mx[qb]));
+        float nm[QB], alpha[QB], rs0[QB], rs1[QB];
+        // ---- the softmax of tile t as 106 micro-stages of 2-4 VALU instructions, dealt over the 32 MFMA slots in a fixed order.
+        // With ONE wave on the SIMD nothing hides a VALU result's latency: an instruction that reads the result of the one just
+        // in front of it stalls the wave (v_exp_f32 above all).  So the stream is software-pipelined over the 32 score pairs of
+        // the wave's two query blocks: A(g) = the two exponent arguments of pair g, B(g) = its two exponentials, C(g) = its
+        // row-sum terms + the packed conversion, issued as A(g), B(g-1), C(g-2); the running maxima (4 interleaved chains of
+        // max3 per query block) come first.  Every micro-stage ends in an empty asm that makes its results opaque: pure
+        // arithmetic is otherwise sunk past the pinned MFMAs to its first use.
+        float pm[QB][4], z0[32], z1[32], e0[32], e1[32];
+        auto max_step = [&](auto qb_c, auto step_c) {         // step 0..3 of the four 8-score chains of query block qb
+            constexpr int qb = decltype(qb_c)::value, step = decltype(step_c)::value;
+#pragma unroll
+            for (int part = 0; part < 4; ++part) {
+                const int kb = part >> 1, b0 = (part & 1) * 8;
+                const f32x16& sv = s_cur[qb][kb];
+                if (step == 0) pm[qb][part] = __builtin_fmaxf(__builtin_fmaxf(sv[b0], sv[b0 + 1]), sv[b0 + 2]);
+                else if (step == 1) pm[qb][part] = __builtin_fmaxf(__builtin_fmaxf(pm[qb][part], sv[b0 + 3]), sv[b0 + 4]);
+                else if (step == 2) pm[qb][part] = __builtin_fmaxf(__builtin_fmaxf(pm[qb][part], sv[b0 + 5]), sv[b0 + 6]);
+                else pm[qb][part] = __builtin_fmaxf(pm[qb][part], sv[b0 + 7]);
+            }
+            asm volatile("" : "+v"(pm[qb][0]), "+v"(pm[qb][1]), "+v"(pm[qb][2]), "+v"(pm[qb][3]));
         };
-        auto max_fin = [&](int qb) {
+        auto max_fin = [&](auto qb_c) {
+            constexpr int qb = decltype(qb_c)::value;
             float lo, hi;
-            both_halves(mx[qb], lo, hi);
+            both_halves(__builtin_fmaxf(__builtin_fmaxf(pm[qb][0], pm[qb][1]), __builtin_fmaxf(pm[qb][2], pm[qb][3])), lo, hi);
             const float m_new = __builtin_fmaxf(m_run[qb], __builtin_fmaxf(lo, hi) * c);
             alpha[qb] = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
             m_run[qb] = m_new;
@@ -268,49 +313,65 @@ __global__ __launch_bounds__(256, 1) void attn_pw64_kernel(AttnArgs p) {
             rs1[qb] = 0.f;
             asm volatile("" : "+v"(nm[qb]), "+v"(alpha[qb]));
         };
-        auto pair = [&](int qb, int i) {
-            const int kb = i >> 3, st = (i >> 2) & 1, j = (i & 3) * 2;
-            const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[qb][kb][st * 8 + j], c, nm[qb]));
-            const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[qb][kb][st * 8 + j + 1], c, nm[qb]));
-            rs0[qb] += e0;
-            rs1[qb] += e1;
-            unsigned pk = __builtin_bit_cast(unsigned, cvt2<T>(e0, e1));
-            // the slot's results made opaque HERE: pure arithmetic is otherwise sunk past the pinned MFMAs to its first use
+        // pair g = 16 qb + i: scores 2 i, 2 i + 1 of the row (i = 8 kb + 4 st + j / 2: the PV product's contraction order)
+        auto stage_a = [&](auto g_c) {
+            constexpr int g = decltype(g_c)::value, qb = g >> 4, i = g & 15, kb = i >> 3, st = (i >> 2) & 1, j = (i & 3) * 2;
+            z0[g] = __builtin_fmaf(s_cur[qb][kb][st * 8 + j], c, nm[qb]);
+            z1[g] = __builtin_fmaf(s_cur[qb][kb][st * 8 + j + 1], c, nm[qb]);
+            asm volatile("" : "+v"(z0[g]), "+v"(z1[g]));
+        };
+        auto stage_b = [&](auto g_c) {
+            constexpr int g = decltype(g_c)::value;
+            e0[g] = __builtin_amdgcn_exp2f(z0[g]);
+            e1[g] = __builtin_amdgcn_exp2f(z1[g]);
+            asm volatile("" : "+v"(e0[g]), "+v"(e1[g]));
+        };
+        auto stage_c = [&](auto g_c) {
+            constexpr int g = decltype(g_c)::value, qb = g >> 4, i = g & 15, kb = i >> 3, st = (i >> 2) & 1, j = (i & 3) * 2;
+            rs0[qb] += e0[g];
+            rs1[qb] += e1[g];
+            unsigned pk = __builtin_bit_cast(unsigned, cvt2<T>(e0[g], e1[g]));
             asm volatile("" : "+v"(pk), "+v"(rs0[qb]), "+v"(rs1[qb]));
             const typename VecOf<T>::v2 e16 = __builtin_bit_cast(typename VecOf<T>::v2, pk);
             p_cur[qb][kb][st][j] = e16[0];
             p_cur[qb][kb][st][j + 1] = e16[1];
+            if (i == 15) l_run[qb] = __builtin_fmaf(l_run[qb], alpha[qb], rs0[qb] + rs1[qb]);
         };
-        auto row_fin = [&](int qb) { l_run[qb] = __builtin_fmaf(l_run[qb], alpha[qb], rs0[qb] + rs1[qb]); };
-        // the VALU work of slot i (0..31): slots 0-1 the maximum of query block 0, slots 2-3 that of block 1 beside the first pairs
-        // of block 0, then one pair per slot: block 0's 16 pairs in slots 2-17, block 1's in slots 16-31
-        auto valu_slot = [&](int i) {
-            if (i == 0) { max_part(0, 0); max_part(0, 1); }
-            if (i == 1) { max_part(0, 2); max_part(0, 3); max_fin(0); }
-            if (i == 2) { max_part(1, 0); max_part(1, 1); }
-            if (i == 3) { max_part(1, 2); max_part(1, 3); max_fin(1); }
-            if (i >= 2 && i < 18) pair(0, i - 2);
-            if (i == 17) row_fin(0);
-            if (i >= 16) pair(1, i - 16);
-            if (i == 31) row_fin(1);
+        // micro-stage k of 106: 0-4 / 5-9 the maxima of query block 0 / 1 (4 chain steps + the finish), then the pair pipeline
+        constexpr int NMICRO = 106;
+        auto micro = [&](auto k_c) {
+            constexpr int k = decltype(k_c)::value;
+            if constexpr (k < 10) {
+                constexpr int qb = k / 5, st = k - qb * 5;
+                if constexpr (st < 4) max_step(std::integral_constant<int, qb>(), std::integral_constant<int, st>());
+                else max_fin(std::integral_constant<int, qb>());
+            } else {
+                constexpr int pidx = k - 10;                   // 0..95: A0 | A1 B0 | (A(g) B(g-1) C(g-2)), g = 2..31 | B31 C30 | C31
+                if constexpr (pidx == 0) stage_a(std::integral_constant<int, 0>());
+                else if constexpr (pidx == 1) stage_a(std::integral_constant<int, 1>());
+                else if constexpr (pidx == 2) stage_b(std::integral_constant<int, 0>());
+                else if constexpr (pidx < 93) {
+                    constexpr int q = pidx - 3, g = 2 + q / 3, w = q - (g - 2) * 3;
+                    if constexpr (w == 0) stage_a(std::integral_constant<int, g>());
+                    else if constexpr (w == 1) stage_b(std::integral_constant<int, g - 1>());
+                    else stage_c(std::integral_constant<int, g - 2>());
+                } else if constexpr (pidx == 93) stage_b(std::integral_constant<int, 31>());
+                else if constexpr (pidx == 94) stage_c(std::integral_constant<int, 30>());
+                else stage_c(std::integral_constant<int, 31>());
+            }
         };
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            if (i < 16) {                                     // S(t+1)[qb][kb] += K(t+1)[kb][ks] Q[qb][ks]: i = 8 kb + 2 ks + qb
-                const int kb = i >> 3, ks = (i >> 1) & 3, qb = i & 1;
-                if (HAS_QK) {
-                    if (ks == 0) mfma_s0(s_nxt[qb][kb], kf[kb][ks], qf[qb][ks]);
-                    else mfma_s(s_nxt[qb][kb], kf[kb][ks], qf[qb][ks]);
-                }
-                PW_PIN();
-                valu_slot(i);
-                if (qb == 1) kf[kb][ks] = *(const v8*)(kbase + k_off[kb][ks]);      // K(t+2) fragment behind its last use
-            } else {                                          // O[qb][db] += V(t-1)[db][kb][st] P(t-1)[qb][kb][st]: i - 16 = 8 db + 4 kb + 2 st + qb
-                const int u = i - 16, db = u >> 3, kb = (u >> 2) & 1, st = (u >> 1) & 1, qb = u & 1;
-                if (HAS_PV) mfma_o(o_acc[qb][db], vf[db][kb][st], p_prv[qb][kb][st]);
-                PW_PIN();
-                valu_slot(i);
-                if (qb == 1) {                                // V(t) fragment behind its last use
+        // fragment f (0-7: K (kb, ks) = (f >> 2, f & 3); 8-15: V^T (db, kb, st)) is used by the MFMAs of slots 2 f and 2 f + 1 and
+        // re-read for the next iteration in slot min(2 f + 3, 31): an LDS read that overwrites a register an in-flight MFMA still
+        // reads as an operand waits for that MFMA (measured: re-read right behind its last use, the 24 fragment reads cost as much as
+        // the whole MFMA stream).  The four LDS-DMA pieces of the iteration go out in slots 1, 9, 17, 25, beside running MFMAs.
+        auto reload = [&](auto f_c) {
+            constexpr int f = decltype(f_c)::value;
+            if constexpr (!(DBG & 0x1000)) {
+                if constexpr (f < 8) {
+                    constexpr int kb = f >> 2, ks = f & 3;
+                    kf[kb][ks] = *(const v8*)(kbase + k_off[kb][ks]);
+                } else {
+                    constexpr int u = f - 8, db = u >> 2, kb = (u >> 1) & 1, st = u & 1;
                     const v4 lo = tr_read<T>(vbase + v_off[db][kb][st][0]);
                     const v4 hi = tr_read<T>(vbase + v_off[db][kb][st][1]);
                     v8 x;
@@ -319,13 +380,40 @@ __global__ __launch_bounds__(256, 1) void attn_pw64_kernel(AttnArgs p) {
                     vf[db][kb][st] = x;
                 }
             }
+        };
+        StaticFor<0, 32>::run([&](auto i_c) {
+            constexpr int i = decltype(i_c)::value;
+            if constexpr (i < 16) {                           // S(t+1)[qb][kb] += K(t+1)[kb][ks] Q[qb][ks]: i = 8 kb + 2 ks + qb
+                constexpr int kb = i >> 3, ks = (i >> 1) & 3, qb = i & 1;
+                if constexpr (HAS_QK && !(DBG & 0x400)) {
+                    if constexpr (ks == 0) mfma_s0(s_nxt[qb][kb], kf[kb][ks], qf[qb][ks]);
+                    else mfma_s(s_nxt[qb][kb], kf[kb][ks], qf[qb][ks]);
+                }
+            } else {                                          // O[qb][db] += V(t-1)[db][kb][st] P(t-1)[qb][kb][st]: i - 16 = 8 db + 4 kb + 2 st + qb
+                constexpr int u = i - 16, db = u >> 3, kb = (u >> 2) & 1, st = (u >> 1) & 1, qb = u & 1;
+                if constexpr (HAS_PV && !(DBG & 0x400)) mfma_o(o_acc[qb][db], vf[db][kb][st], p_prv[qb][kb][st]);
+            }
             PW_PIN();
-        }
+            if constexpr (!(DBG & 0x200)) StaticFor<(i * NMICRO) / 32, ((i + 1) * NMICRO) / 32>::run(micro);
+            if constexpr (i >= 3 && i < 31 && ((i - 3) & 1) == 0) reload(std::integral_constant<int, (i - 3) / 2>());
+            if constexpr (i == 31) { reload(std::integral_constant<int, 14>()); reload(std::integral_constant<int, 15>()); }
+            if constexpr (!(DBG & 0x100)) {
+                if constexpr (i == 1) dma_k_piece(t + 4, 0);
+                if constexpr (i == 9) dma_k_piece(t + 4, 1);
+                if constexpr (i == 17) dma_v_piece(t + 2, 0);
+                if constexpr (i == 25) dma_v_piece(t + 2, 1);
+            }
+            PW_PIN();
+            if constexpr (i == 7) stamp(1);
+            if constexpr (i == 15) stamp(2);
+            if constexpr (i == 23) stamp(3);
+            if constexpr (i == 31) stamp(4);
+        });
         // the older sums follow the new maximum: O (complete up to tile t-1) scales by alpha - rarely, the maximum settles within
         // the first tiles.  O sits in AGPRs behind asm MFMAs: pad the read by hand.
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb)
-            if (!__all(alpha[qb] == 1.0f)) {
+            if (!(DBG & (1 | 0x200)) && ((DBG & 8) || !__all(alpha[qb] == 1.0f))) {
                 // (the operands keep every read of O below the pad: hoisted above it they would sit right behind an asm MFMA)
                 asm volatile("s_nop 15\n\ts_nop 15" : "+a"(o_acc[qb][0]), "+a"(o_acc[qb][1]));
 #pragma unroll
@@ -334,9 +422,11 @@ __global__ __launch_bounds__(256, 1) void attn_pw64_kernel(AttnArgs p) {
                     for (int e = 0; e < 16; ++e) o_acc[qb][db][e] *= alpha[qb];
                 asm volatile("s_nop 7" : "+a"(o_acc[qb][0]), "+a"(o_acc[qb][1]));      // v_accvgpr_write -> MFMA SrcC
             }
+        stamp(5);
     };
     typedef std::true_type yes;
     typedef std::false_type no;
+    (void)0;
     // tile 0 has no PV yet; the last tile (partial) no further QK^T; ntiles >= 3
     iter(0, sA, sB, pA, pB, yes(), no(), no());
     int t = 1;
@@ -363,6 +453,15 @@ __global__ __launch_bounds__(256, 1) void attn_pw64_kernel(AttnArgs p) {
     asm volatile("s_nop 15\n\ts_nop 15" : "+a"(o_acc[0][0]), "+a"(o_acc[0][1]), "+a"(o_acc[1][0]), "+a"(o_acc[1][1]));   // O is read by the VALU below
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA pieces requested past the last tile
 
+    if constexpr (DBG & 0x2000) {
+        if (blockIdx.x == 0 && tid == 0) {
+            unsigned long long* dst = (unsigned long long*)p.o;      // (timing build: the output is not valid anyway)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dst[k] = st_acc[k];
+            dst[6] = (unsigned long long)ntiles;
+        }
+        return;
+    }
     // ---- finalise: lane (r, hh) holds O[q = q0 + 32 qb + r][32 db + 8 (e >> 2) + 4 hh + (e & 3)]
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
@@ -388,26 +487,37 @@ __global__ __launch_bounds__(256, 1) void attn_pw64_kernel(AttnArgs p) {
 #undef PW_MFMA_NAME
 }
 
-template <class T>
+template <class T, int DBG = 0>
 int launch_pw64(const AttnArgs& a, int batch, hipStream_t st) {
     constexpr int lds = 2 * PW_RING * PW_TILE_BYTES;
     static bool attr_dev[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_dev[dev]) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_pw64_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn_pw64_kernel<T, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_dev[dev] = true;
     }
     dim3 grid(((a.sq + 255) / 256) * a.heads * batch);
-    hipLaunchKernelGGL((attn_pw64_kernel<T>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((attn_pw64_kernel<T, DBG>), grid, dim3(256), lds, st, a);
     return (int)hipGetLastError();
 }
 
 }  // namespace
 
 // entry for attention.hip: -1 when this form does not apply
-int tdc_attention_pw(const AttnArgs& a, int batch, int dtype, hipStream_t st) {
+int tdc_attention_pw(const AttnArgs& a, int batch, int dtype, hipStream_t st, int dbg) {
     if (a.bias || !a.vec_ok || a.sq < 256 || a.sk < 3 * PW_KT || a.d != 64) return -1;
     if ((a.k_rs & 7) || (a.v_rs & 7)) return -1;
+    // timing ablations (tools/debug_attn_pw.py; results invalid): form = 2 + bits
+    if (dbg == 0x100) return launch_pw64<f16, 0x100>(a, batch, st);
+    if (dbg == 0x200) return launch_pw64<f16, 0x200>(a, batch, st);
+    if (dbg == 0x400) return launch_pw64<f16, 0x400>(a, batch, st);
+    if (dbg == 0x800) return launch_pw64<f16, 0x900>(a, batch, st);       // no sync needs no DMA either
+    if (dbg == 0x1000) return launch_pw64<f16, 0x1000>(a, batch, st);
+    if (dbg == 0x1100) return launch_pw64<f16, 0x1b00>(a, batch, st);     // MFMAs + softmax only
+    if (dbg == 0x1300) return launch_pw64<f16, 0x1b00 | 0x200>(a, batch, st);   // MFMAs only
+    if (dbg == 0x2000) return launch_pw64<f16, 0x2000>(a, batch, st);           // full kernel with cycle stamps
+    if (dbg == 0x2100) return launch_pw64<f16, 0x2100>(a, batch, st);           // ... without DMA
+    if (dbg == 0x3000) return launch_pw64<f16, 0x3000>(a, batch, st);           // ... without fragment reads
     return dtype == TDC_F16 ? launch_pw64<f16>(a, batch, st) : launch_pw64<bf16>(a, batch, st);
 }

@@ -7,7 +7,8 @@ import sys
 
 def main(path):
     lines = open(path).read().splitlines()
-    starts = [i for i, l in enumerate(lines) if re.match(r"_ZN.*attn_pw\w*kernel.*:", l)]
+    # the product instantiations only (debug / timing variants carry a non-zero DBG template argument: ...Li<N>E...)
+    starts = [i for i, l in enumerate(lines) if re.match(r"_ZN.*attn_pw\w*kernel\w*Li0EEEv.*:", l)]
     ends = [i for i, l in enumerate(lines) if "s_endpgm" in l]
     bad = n = 0
     for s0 in starts:
@@ -30,7 +31,45 @@ def main(path):
                             print("line %d: destination of the read at line %d touched before lgkmcnt(0): %s" % (j + 1, i + 1, code.strip()))
                 j += 1
     print("%d asm transposed reads, %d violations" % (n, bad))
-    return 1 if bad else 0
+    # asm MFMAs (between ;;#ASMSTART / ;;#ASMEND): the compiler pads nothing behind them, so for 18 wait states (16-pass XDL write ->
+    # VALU / memory access) no instruction but another MFMA may touch the destination tuple - neither a read nor a copy
+    nm = bad2 = 0
+    for s0 in starts:
+        e0 = min(e for e in ends if e > s0)
+        in_asm = False
+        for i in range(s0, e0):
+            if "#ASMSTART" in lines[i]:
+                in_asm = True
+            elif "#ASMEND" in lines[i]:
+                in_asm = False
+            m = re.search(r"v_mfma\w+ ([av])\[(\d+):(\d+)\]", lines[i]) if in_asm else None
+            if not m:
+                continue
+            nm += 1
+            kind, lo, hi = m.group(1), int(m.group(2)), int(m.group(3))
+            states, j = 0, i + 1
+            while j < e0 and states < 18:
+                code = lines[j].split(";")[0].strip()
+                j += 1
+                if not code or code.startswith("."):
+                    continue
+                mm = re.match(r"s_nop (\d+)", code)
+                if mm:
+                    states += int(mm.group(1)) + 1
+                    continue
+                if code.startswith("v_mfma"):
+                    states += 8          # an MFMA holds the issue port for at least 8 cycles (4 cycles per wait state: >= 2)
+                    continue
+                states += 1
+                touched = any(lo <= int(r) <= hi for r in re.findall(r"\b%s(\d+)\b" % kind, code)) or \
+                    any(not (int(b) < lo or int(a) > hi) for a, b in re.findall(r"\b%s\[(\d+):(\d+)\]" % kind, code))
+                if touched:
+                    bad2 += 1
+                    if bad2 <= 10:
+                        print("line %d: destination %s[%d:%d] of the asm MFMA at line %d touched %d wait states later: %s"
+                              % (j, kind, lo, hi, i + 1, states, code))
+    print("%d asm MFMAs, %d destination-hazard violations" % (nm, bad2))
+    return 1 if (bad or bad2) else 0
 
 
 if __name__ == "__main__":
