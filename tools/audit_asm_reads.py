@@ -8,7 +8,7 @@ import sys
 def main(path):
     lines = open(path).read().splitlines()
     # the product instantiations only (debug / timing variants carry a non-zero DBG template argument: ...Li<N>E...)
-    starts = [i for i, l in enumerate(lines) if re.match(r"_ZN.*attn_pw\w*kernel\w*Li0EEEv.*:", l)]
+    starts = [i for i, l in enumerate(lines) if re.match(r"_ZN.*attn_pw\w*kernel\w*EEv.*:", l)]
     ends = [i for i, l in enumerate(lines) if "s_endpgm" in l]
     bad = n = 0
     for s0 in starts:
