@@ -27,7 +27,7 @@ MFMA_PEAK_TFLOPS = 2500.0   # dense bf16/fp16 MFMA peak, /opt/skills/guides/MI35
 # what back-to-back bf16 16x16x32 MFMAs on dense random REGISTER operands sustain at the chip's power limit (no memory traffic;
 # all-zero operands: 2448): tools/mfma_power.cpp, profiles/r02_mfma_power.log.  Reported beside `frac`, never instead of it.
 MFMA_DENSE_SUSTAINED_TFLOPS = 1899.0
-PMC_SUMMARY = "r03_gemm_pmc_summary.json"   # profiles/: counters of the current code (tools/run_gemm_pmc.sh), see `traffic_source`
+PMC_SUMMARY = "r04_gemm_pmc_summary.json"   # profiles/: counters of the current code (tools/run_gemm_pmc.sh), see `traffic_source`
 
 
 def model_cfg(H, K, T):
@@ -432,6 +432,8 @@ def main():
             kv_busy = max((r.get("mfma_busy_frac", 0) for r in summ["shapes"] if r["N"] >= 9216 and r["K"] == H), default=None)
             traffic_source = "replayed, not measured in this run: profiles/%s (tools/gemm_pmc.cpp on this launch list, " \
                              "collected at commit %s)" % (PMC_SUMMARY, summ.get("collected_at_commit", "?"))
+            if summ.get("gemm_ms_per_step_at_collection"):   # staleness check: this run's GEMM time / the replayed run's
+                traffic_source += "; live / replayed GEMM time per step = %.3f" % (g_ms / summ["gemm_ms_per_step_at_collection"])
     # fp8 runs: the dense f8f6f4 MFMA peak (5 PFLOP/s) when every tower GEMM runs on e4m3 operands (level 2); at level 1
     # a third of the GEMM FLOPs stay in bf16, the bf16 peak is kept as the (conservative) yardstick
     peak = 2.0 * MFMA_PEAK_TFLOPS if (args.dtype == "fp8" and args.fp8_level >= 2) else MFMA_PEAK_TFLOPS

@@ -54,6 +54,7 @@ int main(int argc, char** argv) {
         d.c_pad8 = pad8 ? 1 : 0;
         d.M = M; d.N = N; d.K = K; d.dtype = TDC_BF16; d.out_f32 = outf32; d.act = act;
         if (res) { d.res = C; d.ldres = N; d.res_f32 = outf32; }   // in-place residual stream update
+        if (res == 2) d.c16_dtype_p1 = TDC_F16 + 1;                // the towers' fp16 residual stream beside bf16 operands
         float *stats = nullptr, *c1 = nullptr;
         if (fp8) {
             std::vector<float> hs((size_t)M * 2);

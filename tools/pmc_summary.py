@@ -37,6 +37,17 @@ def fold(values):
 
 
 import os
+
+
+def kernel_ms():
+    """per-shape kernel duration (ms) from the kernel trace of the GRBM_GUI_ACTIVE pass (any pass would do: one counter
+    per pass costs the kernel nothing measurable): lets bench.py print live / replayed GEMM time, so staleness shows"""
+    f = glob.glob("%s/*pmc_GRBM_GUI_ACTIVE*kernel_trace.csv" % out)
+    rows = [r for r in csv.DictReader(open(f[0])) if "gemm" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    return fold([(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6 for r in rows])
+
+
 fetch, write = fold(per_dispatch("FETCH_SIZE")), fold(per_dispatch("WRITE_SIZE"))
 assert len(fetch) == len(shapes) == len(write), (len(fetch), len(write), len(shapes))
 try:    # MFMA pipe occupancy: busy cycles summed over the 1024 SIMDs / (1024 x kernel cycles); GRBM_GUI_ACTIVE is summed
@@ -51,6 +62,7 @@ res = []
 for (M, N, K, act, has_res, of32, count), fk, wk in zip(shapes, fetch, write):
     traffic = (2.0 * fk + wk) * 1024.0
     n_out = N // 2 if act == 3 else N
+    # has_res: 0 none, 1 fp32 residual (with an fp32 output), 2 16-bit residual (with a 16-bit output): read + write of C's type
     alg = 2.0 * (M * K + N * K) + M * n_out * (4 if of32 else 2) * (2 if has_res else 1)
     row = dict(M=M, N=N, K=K, act=act, res=has_res, out_f32=of32, launches_per_step=count,
                hbm_bytes=traffic, algorithmic_bytes=alg, ratio=round(traffic / alg, 3))
@@ -74,6 +86,13 @@ if mfma is not None:
 import os
 if os.path.exists(shapes_file + ".args.json"):
     summary["bench_args"] = json.load(open(shapes_file + ".args.json"))
+try:
+    ms = kernel_ms()
+    for r, m in zip(res, ms):
+        r["kernel_ms"] = round(m, 4)
+    summary["gemm_ms_per_step_at_collection"] = round(sum(m * r["launches_per_step"] for r, m in zip(res, ms)), 2)
+except Exception as e:  # noqa: BLE001
+    print("no kernel trace:", e)
 summary["collected_at_commit"] = os.environ.get("TDC_COMMIT", "unknown")
 summary["collected_by"] = "tools/run_gemm_pmc.sh (torch-free replay tools/gemm_pmc.cpp, one counter per rocprofv3 pass)"
 json.dump(summary, open(out + "/gemm_pmc_summary.json", "w"), indent=1)
