@@ -39,6 +39,12 @@ def main():
         print("   behind the residual GEMM: %8.3f ms  %7.1f GB/s" % (ms, rows * cols * 6 / ms / 1e6), flush=True)
         del a, w
         del x, y
+        # the towers' 16-bit residual stream (round 4): fp16 rows in, bf16 rows out, 4 algorithmic bytes per element
+        x = torch.randn(rows, cols, device="cuda", generator=g).half()
+        y = torch.empty(rows, cols, device="cuda", dtype=dtype)
+        ms = timeit(lambda: ops.layernorm(x, gm, bt, 1e-6, cols, dtype, y16=y), iters=20)
+        print("   fp16 rows -> bf16 rows: %8.3f ms  %7.1f GB/s" % (ms, rows * cols * 4 / ms / 1e6), flush=True)
+        del x, y
 
 
 if __name__ == "__main__":

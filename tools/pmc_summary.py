@@ -17,23 +17,14 @@ def per_dispatch(counter):
     return [float(r["Counter_Value"]) for r in rows]
 
 
-def n_dispatches(shape):
-    """kernel launches tdc_gemm makes for one call (csrc/gemm.hip): N = 256 t + 128 goes out as the 256 x 256 kernel on the first
-    256 t columns + the 128 x 128 kernel on the last 128"""
-    M, N, K, act, has_res, of32, count = shape
-    fp8 = bool(os.environ.get("TDC_PMC_FP8"))
-    return 1    # (round 3's column split of N = 256 t + 128 was removed again: one launch per call)
+REPS = int(__import__("os").environ.get("PMC_REPS", "2"))   # launches per shape in the replay (tools/run_gemm_pmc.sh)
 
 
 def fold(values):
-    """per-dispatch counter values -> one value per shape (the launches of a split call summed)"""
-    out_, i = [], 0
-    for shp in shapes:
-        n = n_dispatches(shp)
-        out_.append(sum(values[i:i + n]))
-        i += n
-    assert i == len(values), (i, len(values))
-    return out_
+    """per-dispatch values -> one value per shape: the LAST of the shape's REPS launches (the first one pays for the code
+    object, cold TLBs and freshly allocated pages: 10-15 % longer)"""
+    assert len(values) == REPS * len(shapes), (len(values), REPS, len(shapes))
+    return [values[REPS * i + REPS - 1] for i in range(len(shapes))]
 
 
 import os

@@ -1,6 +1,7 @@
 #!/bin/bash
 # MFMA-busy counters of the fp8-operand GEMM instances on the tower shapes (run on the MI355X box from the repo root)
 set -e
+export PMC_REPS=1
 SHAPES=tools/gemm_shapes_T512_fp8.txt
 OUT=gpurun_out/pmc_fp8
 mkdir -p $OUT
