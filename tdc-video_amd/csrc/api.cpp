@@ -251,7 +251,7 @@ extern "C" int tdc_qformer_fwd(const tdc_qformer_model* m, const void* enc, int 
                          ident, ident, stream));
     }
     tdc_profile_tag(0);
-    const float scale = 1.0f / sqrtf((float)hd);
+    const float scale = (float)(1.0 / sqrt((double)hd));          // float(hd ** -0.5), correctly rounded (1.0f / sqrtf is 1 ulp off at 72, 96)
     for (int l = 0; l < m->n_layers; ++l) {
         const tdc_qformer_layer& L = m->layers_host[l];
         bool q16 = false;   // this layer's query rows between the cross-attention output and the FFN LayerNorm: 16-bit only (t32 holds 16-bit rows)
@@ -366,7 +366,7 @@ extern "C" int tdc_vit_fwd(const tdc_vit_model* m, const void* px, int px_f32, i
         hipError_t e = hipMemsetAsync(attn, 0, (size_t)rows * Dp * 2, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
     }
-    const float scale = 1.0f / sqrtf((float)m->head_dim);
+    const float scale = (float)(1.0 / sqrt((double)m->head_dim));  // float(head_dim ** -0.5), correctly rounded (1.0f / sqrtf is 1 ulp off at 72)
     const int out_dt = m->out_dtype_p1 ? m->out_dtype_p1 - 1 : dt;
     if (m->res_dtype_p1) {
         // 16-bit residual stream (tdc_vit_model.res_dtype_p1): x lives in the x32 region as rows of type `rt`; the out-projection

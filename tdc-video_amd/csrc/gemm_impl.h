@@ -1607,6 +1607,45 @@ inline int persistent_grid() {
     return grid[dev];
 }
 
+// Group height of the tile order, per launch.  The 32 workgroups an XCD runs at a time take 32 CONSECUTIVE tile ids of the XCD's
+// chunk (persistent kernel: ids base + l + 32 j, round j), so the operand panels that stream through that L2 in a round are the
+// distinct tile rows + tile columns of a window of 32 ids.  With GROUP_M x tiles_n not a multiple of 32 the windows straddle
+// groups (N = 1152 at GROUP_M = 8: 17.4 panels per window on average instead of 12); the host walks the first windows of a chunk
+// with the kernel's own id -> tile arithmetic and takes the height with the fewest panels: 1 (row-major) for <= 7 column tiles
+// (12.3 panels at 5 or 6 columns), 4 or 8 for the wide GEMMs.  PMC, fabric bytes / algorithmic bytes: see NOTES round 4.
+inline int choose_group_m(int tiles_m, int tiles_n) {
+    static int memo_m[16], memo_n[16], memo_g[16], memo_cnt = 0;      // (a handful of shapes per process)
+    for (int i = 0; i < memo_cnt; ++i)
+        if (memo_m[i] == tiles_m && memo_n[i] == tiles_n) return memo_g[i];
+    const int cand[4] = {4, 8, 1, 2};                                   // ties go to the earlier entry
+    const long long n = (long long)tiles_m * tiles_n;
+    const long long len = n / 8 < 32 * 256 ? n / 8 : 32 * 256;           // up to 256 rounds of XCD 0's chunk
+    int best = tiles_n >= 8 ? 4 : 8;
+    double best_cost = 1e30;
+    for (int c = 0; c < 4 && len >= 32; ++c) {
+        const int G = cand[c];
+        long long panels = 0;
+        for (long long j = 0; j + 32 <= len; j += 32) {
+            int rows[32], cols[32], nr = 0, nc = 0;
+            for (int i = 0; i < 32; ++i) {
+                const long long id = j + i;
+                const long long per = (long long)G * tiles_n, grp = id / per, within = id - grp * per;
+                const int first = (int)grp * G, h = (tiles_m - first < G) ? tiles_m - first : G;
+                const int tn = (int)(within / h), tm = first + (int)(within - (long long)tn * h);
+                bool fr = false, fc = false;
+                for (int q = 0; q < nr; ++q) fr |= rows[q] == tm;
+                for (int q = 0; q < nc; ++q) fc |= cols[q] == tn;
+                if (!fr) rows[nr++] = tm;
+                if (!fc) cols[nc++] = tn;
+            }
+            panels += nr + nc;
+        }
+        if ((double)panels < best_cost * 0.95) { best_cost = (double)panels; best = G; }   // 5 % hysteresis towards the earlier entry
+    }
+    if (memo_cnt < 16) { memo_m[memo_cnt] = tiles_m; memo_n[memo_cnt] = tiles_n; memo_g[memo_cnt] = best; ++memo_cnt; }
+    return best;
+}
+
 // kernel choice: the 256^2 8-phase kernel needs enough tiles to fill the 256 CUs (diagnostics builds: TDC_GEMM_FORCE=128|256)
 inline bool use_256(int M, int N, int K) {
 #ifdef TDC_GEMM_DIAG
@@ -1656,16 +1695,12 @@ int launch(const tdc_gemm_desc* d, hipStream_t st, bool force128 = false) {
     if (!force128 && use_256(a.M, a.N, a.K)) {
         a.tiles_m = (a.M + 255) / 256;
         a.tiles_n = (a.N + 255) / 256;
-        {   // group height of the tile order: the 32 concurrent tiles of an XCD form a GROUP_M x (32 / GROUP_M) patch that walks
-            // along the columns of its GROUP_M tile rows.  With >= 8 column tiles a 4 x 8 patch keeps the 4 activation panels
-            // L2-resident from one round to the next (PMC, fabric bytes / algorithmic bytes: N = 8192 5.06 -> 4.22, N = 3456
-            // 3.22 -> 2.51, N = 4352 2.59 -> 2.28; 0.8 % faster); the 5- and 6-column GEMMs are better off at 8 (2.39 vs 2.63).
-            // The order never changes a result.  (Diagnostics builds: TDC_GEMM_GROUP_M overrides.)
-            a.group_m = a.tiles_n >= 8 ? 4 : 8;
+        // group height of the tile order (choose_group_m above): fewest operand panels per window of 32 concurrent tiles.
+        // The order never changes a result.  (Diagnostics builds: TDC_GEMM_GROUP_M overrides.)
+        a.group_m = choose_group_m(a.tiles_m, a.tiles_n);
 #ifdef TDC_GEMM_DIAG
-            { const char* e = getenv("TDC_GEMM_GROUP_M"); if (e && atoi(e) > 0) a.group_m = atoi(e); }
+        { const char* e = getenv("TDC_GEMM_GROUP_M"); if (e && atoi(e) > 0) a.group_m = atoi(e); }
 #endif
-        }
         // hipFuncSetAttribute is per device: one flag per device and instantiation
         const int dev = current_device();
         static bool attr256_dev[kMaxDev];

@@ -14,8 +14,8 @@ def timeit(fn, n=20):
     return a.elapsed_time(b) / n
 
 dev = torch.device("cuda", 0)
-for (M, N, K) in [(186624, 1152, 1152), (186624, 3456, 1152), (186624, 4352, 1152), (186624, 1152, 4352),
-                  (186880, 1536, 1536), (186880, 4608, 1536), (186880, 8192, 1536), (186880, 1536, 4096)]:
+for (M, N, K) in [(373248, 1152, 1152), (373248, 3456, 1152), (373248, 4352, 1152), (373248, 1152, 4352),
+                  (373760, 1536, 1536), (373760, 4608, 1536), (373760, 8192, 1536), (373760, 1536, 4096)]:
     A = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
     W = torch.randn(N, K, device=dev, dtype=torch.bfloat16) * 0.02
     C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
