@@ -46,6 +46,9 @@ __device__ __forceinline__ float other_half(float v) {
 }
 
 constexpr int KT32 = 64;   // keys per tile (2 key blocks of 32)
+#ifndef ATTN32_THR
+#define ATTN32_THR 8.0f
+#endif
 
 // DK: QK^T contraction width (64 or 80), NDB: output blocks of 32 columns (2 or 3), QB: 32-row query blocks per wave
 template <class T, int DK, int NDB, int QB>
@@ -219,7 +222,10 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(AttnArgs p) {
                 for (int e = 0; e < 16; e += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[qb][1][e]), s[qb][1][e + 1]);
             }
             mx = fmaxf(mx, other_half(mx));
-            const float m_new = fmaxf(m_run[qb], mx * c);
+            // deferred rescale (cdna_hip_programming.md T13): the running maximum only follows the tile's when that exceeds it by
+            // more than ATTN32_THR (base-2 exponent units) - P stays <= 2^THR, O and l are rescaled in the first tile or two only
+            const float m_cand = mx * c;
+            const float m_new = (m_cand > m_run[qb] + ATTN32_THR) ? m_cand : m_run[qb];
             const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
             m_run[qb] = m_new;
             // exponent arguments and row sums on register pairs (v_pk_fma_f32 / v_pk_add_f32: one issue slot per two values)

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
+#include <mutex>
 
 // Diagnostic switch of the epilogue (timing experiments only), set through tdc_gemm_set_debug() - never from the
 // environment, so a stale variable cannot silently change what the production library computes.  Defined in gemm.hip.
@@ -1614,7 +1615,9 @@ inline int persistent_grid() {
 // with the kernel's own id -> tile arithmetic and takes the height with the fewest panels: 1 (row-major) for <= 7 column tiles
 // (12.3 panels at 5 or 6 columns), 4 or 8 for the wide GEMMs.  PMC, fabric bytes / algorithmic bytes: see NOTES round 4.
 inline int choose_group_m(int tiles_m, int tiles_n) {
-    static int memo_m[16], memo_n[16], memo_g[16], memo_cnt = 0;      // (a handful of shapes per process)
+    static int memo_m[32], memo_n[32], memo_g[32], memo_cnt = 0;      // (a handful of shapes per process)
+    static std::mutex memo_mu;                                         // tdc_gemm is called from several host threads (dist.py)
+    std::lock_guard<std::mutex> lock(memo_mu);
     for (int i = 0; i < memo_cnt; ++i)
         if (memo_m[i] == tiles_m && memo_n[i] == tiles_n) return memo_g[i];
     const int cand[4] = {4, 8, 1, 2};                                   // ties go to the earlier entry
@@ -1642,7 +1645,7 @@ inline int choose_group_m(int tiles_m, int tiles_n) {
         }
         if ((double)panels < best_cost * 0.95) { best_cost = (double)panels; best = G; }   // 5 % hysteresis towards the earlier entry
     }
-    if (memo_cnt < 16) { memo_m[memo_cnt] = tiles_m; memo_n[memo_cnt] = tiles_n; memo_g[memo_cnt] = best; ++memo_cnt; }
+    if (memo_cnt < 32) { memo_m[memo_cnt] = tiles_m; memo_n[memo_cnt] = tiles_n; memo_g[memo_cnt] = best; ++memo_cnt; }
     return best;
 }
 
