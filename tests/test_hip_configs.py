@@ -61,6 +61,9 @@ def _embed_fn(H, seed=3):
     return lambda ids: table[torch.as_tensor(ids, dtype=torch.long) % 64]
 
 
+_ORACLE_CACHE = {}
+
+
 # ------------------------------------------------------------------------------------------------------------ config 1
 @pytest.mark.parametrize("mns,expect_qformer", [(24, False), (2, True)])
 def test_config1_8frames_336px_end_to_end_vs_oracle(mns, expect_qformer):
@@ -128,12 +131,12 @@ def _full_depth_reference(px_s, px_d, T, H, K, mns):
     return _FULL_DEPTH_REF[key]
 
 
-@pytest.mark.parametrize("tower_dtype,res_dtype,px", [
-    (torch.float16, None, 336), (torch.bfloat16, None, 336),           # config 1, fp32 residual stream (rounds 2-3)
-    (torch.float16, torch.float16, 336),                               # ... the reference's own arithmetic: fp16 throughout
-    (torch.bfloat16, torch.float16, 336),                              # ... the bench's type
-    (torch.bfloat16, torch.float16, 384),                              # the BENCH's own geometry: 384 / 378 px, 27 x 27 -> 24 x 24
-])
+@pytest.mark.parametrize("tower_dtype,res_dtype,px", [                 # all at the BENCH's own geometry: 384 / 378 px, 27 x 27 -> 24 x 24
+    (torch.float16, None, 384), (torch.bfloat16, None, 384),           # fp32 residual stream (rounds 2-3)
+    (torch.float16, torch.float16, 384),                               # the reference's own arithmetic: fp16 throughout
+    (torch.bfloat16, torch.float16, 384),                              # the bench's type
+])   # (336 px - no 27 -> 24 resample, round 3's geometry - was measured for all of these in rounds 3-4: DESIGN.md section 2,
+     #  profiles/r04_config1_full_depth_test.log; one geometry = one run of the fp32 oracle = a minute of the suite)
 def test_config1_full_depth_end_to_end_vs_oracle(tower_dtype, res_dtype, px):
     """BASELINE config 1 with NOTHING cut: 8 frames, pixels -> 27-layer SigLIP / 40-layer DINOv2 -> connector -> Q-Former
     (K = 144, max_num_segments = 2 so that the 8 frames are segmented and compressed) -> emitted tokens, against
@@ -209,9 +212,10 @@ def test_config2_336px_towers_full_depth_vs_oracle(dtype, tol):
     Ws = {k[len("vision_tower_aux_list.0.vision_tower."):]: v for k, v in sd.items() if k.startswith("vision_tower_aux_list.0.")}
     Wd = {k[len("vision_tower_aux_list.1.vision_tower."):]: v for k, v in sd.items() if k.startswith("vision_tower_aux_list.1.")}
     assert Ws["embeddings.position_embedding.weight"].shape[0] == 576
-    with torch.no_grad():
-        ref_s, _ = orc.siglip_tower(xs, Ws, 16)
-        ref_d, _ = orc.dino_tower(xd, Wd, 24)
+    if "cfg2_towers" not in _ORACLE_CACHE:     # the same weights and inputs in both cases: one run of the (slow) fp32 oracle
+        with torch.no_grad():
+            _ORACLE_CACHE["cfg2_towers"] = (orc.siglip_tower(xs, Ws, 16)[0], orc.dino_tower(xd, Wd, 24)[0])
+    ref_s, ref_d = _ORACLE_CACHE["cfg2_towers"]
     got_s = enc.tower("siglip", xs.cuda())[:, :1152].reshape(2, 576, 1152)
     got_d = enc.tower("dino", xd.cuda())[:, :1536].reshape(2, 576, 1536)
     es, ed = _rel(got_s, ref_s), _rel(got_d, ref_d)

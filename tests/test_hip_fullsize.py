@@ -132,6 +132,9 @@ def _rel(a, b):
     return float((a.float().cpu() - b.float().cpu()).abs().max()) / max(1e-6, float(b.abs().max()))
 
 
+_ORACLE_CACHE = {}
+
+
 @pytest.fixture(scope="module")
 def full_sd():
     import bench
@@ -159,9 +162,10 @@ def test_fullsize_towers_vs_oracle(full_sd, dtype, tol, fuse, monkeypatch):
     xd = torch.rand(2, 3, 378, 378, generator=g) * 2 - 1
     Ws = {k[len("vision_tower_aux_list.0.vision_tower."):]: v for k, v in sd.items() if k.startswith("vision_tower_aux_list.0.")}
     Wd = {k[len("vision_tower_aux_list.1.vision_tower."):]: v for k, v in sd.items() if k.startswith("vision_tower_aux_list.1.")}
-    with torch.no_grad():
-        ref_s, _ = orc.siglip_tower(xs, Ws, 16)
-        ref_d, _ = orc.dino_tower(xd, Wd, 24)
+    if "towers" not in _ORACLE_CACHE:          # the same inputs in all four cases: one run of the (slow) fp32 oracle
+        with torch.no_grad():
+            _ORACLE_CACHE["towers"] = (orc.siglip_tower(xs, Ws, 16)[0], orc.dino_tower(xd, Wd, 24)[0])
+    ref_s, ref_d = _ORACLE_CACHE["towers"]
     got_s = enc.tower("siglip", xs.cuda())[:, :1152].reshape(2, 576, 1152)
     got_d = enc.tower("dino", xd.cuda())[:, :1536].reshape(2, 576, 1536)
     es, ed = _rel(got_s, ref_s), _rel(got_d, ref_d)
