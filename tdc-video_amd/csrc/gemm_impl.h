@@ -919,6 +919,9 @@ __device__ __forceinline__ void epi_staged32(const GemmArgs& p, f32x4 (&acc)[8][
 // lane reads back 8 consecutive columns of one row (two 16-byte LDS reads), adds 8 residual values it loaded with ONE 16-byte
 // load, and stores 16 bytes: one wave instruction = 8 rows x 128 B on either side.  The residual loads run RING units (8 rows)
 // ahead of their use.  ROWS = rows staged per pass (16: 4 KiB region, 32: 8 KiB of the 16-KiB region).
+#ifndef TDC_RMW16_RING
+#define TDC_RMW16_RING 8      // residual loads in flight per wave (of the 16 a 128 x 64 sub-tile needs)
+#endif
 template <class TC, int ROWS, bool LB, int RING>
 __device__ __forceinline__ void epi_staged_rmw16(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase, int nbase,
                                                  int lane, const EpiLane& el) {
@@ -1045,8 +1048,8 @@ __device__ __forceinline__ bool epilogue_staged_f(const GemmArgs& p, f32x4 (&acc
     else if (res == 2) {
         if (FOLD || (p.N & 7) || (p.ldres & 7) || ((uintptr_t)p.res & 15)) return false;
         constexpr int RR = SMALL ? 16 : 32;
-        if (p.ctype == TDC_F16) epi_staged_rmw16<f16, RR, SMALL, 8>(p, acc, region, mbase, nbase, lane, el);
-        else epi_staged_rmw16<bf16, RR, SMALL, 8>(p, acc, region, mbase, nbase, lane, el);
+        if (p.ctype == TDC_F16) epi_staged_rmw16<f16, RR, SMALL, TDC_RMW16_RING>(p, acc, region, mbase, nbase, lane, el);
+        else epi_staged_rmw16<bf16, RR, SMALL, TDC_RMW16_RING>(p, acc, region, mbase, nbase, lane, el);
     }
     else epi_staged16<T, 0, 0, R16, SMALL, FOLD>(p, acc, region, mbase, nbase, lane, el);
     return true;

@@ -1,4 +1,5 @@
-"""Per tower-GEMM type (real epilogue: fp32 residual RMW / GELU / SwiGLU / plain 16-bit): time of the whole kernel vs the
+"""Per tower-GEMM type (real epilogue: residual read-modify-write - fp16 stream by default, third argument "fp32" for the
+fp32 stream of rounds 1-3 - / GELU / SwiGLU / plain 16-bit): time of the whole kernel vs the
 same launch with the epilogue skipped (tdc_gemm_set_debug(1)), i.e. the share of the C-tile drain.  bf16, one MI355X.
 With a second argument N: also the same launch under tdc_gemm_set_debug(N) (A/B of an epilogue experiment switch)."""
 import math
@@ -16,6 +17,7 @@ from tools.bench_ops import timeit  # noqa: E402
 def main():
     frames = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     alt = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    res32 = len(sys.argv) > 3 and sys.argv[3] == "fp32"
     dtype = torch.bfloat16
     g = torch.Generator(device="cuda").manual_seed(0)
     Ms, Md = frames * 729, frames * 730
@@ -37,7 +39,11 @@ def main():
         n_out = N // 2 if act == L.ACT_SWIGLU else N
         if res:
             x = torch.randn(M, N, device="cuda", generator=g)
-            fn = lambda: ops.gemm(a, w, bias=bias, res=x, out=x, out_f32=True)
+            if res32:
+                fn = lambda: ops.gemm(a, w, bias=bias, res=x, out=x, out_f32=True)
+            else:
+                x = x.half()
+                fn = lambda: ops.gemm(a, w, bias=bias, res=x, out=x)
         else:
             out = torch.empty(M, n_out, device="cuda", dtype=dtype)
             fn = lambda: ops.gemm(a, w, bias=bias, act=act, out=out)
