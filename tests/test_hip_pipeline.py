@@ -581,6 +581,41 @@ def test_towers_16bit_residual_stream(dtype, rdtype):
         assert torch.count_nonzero(a[:, t.dim:]) == 0
 
 
+def test_native_tower_composite_is_graph_capturable():
+    """tdc_vit_fwd allocates nothing and launches everything on the caller's stream: a HIP graph captured around it (through
+    torch.cuda.CUDAGraph) replays to the same bits, also on new pixels written into the captured input buffer."""
+    import tdc_video_amd  # noqa: F401
+    from tdc_video_amd import weights as Wt
+    from tdc_video_amd.pipeline import VideoEncoder
+    W, o = load_fixture("siglip_small.npz")
+    enc = VideoEncoder.__new__(VideoEncoder)
+    enc.dtype, enc.dev, enc.tower_batch = torch.float16, torch.device("cuda"), 4
+    enc.tower_res_dtype = torch.float16
+    enc._tables = {}
+    enc.out_grid = [8, 8]
+    enc.towers = {"siglip": Wt.prep_siglip(W, 4, torch.float16, enc.dev)}
+    enc.native_towers = True
+    px = torch.from_numpy(o["pixels"]).cuda()
+    want = enc.tower("siglip", px).clone()              # warm-up: workspace, cached tables, kernel attributes
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        enc.tower("siglip", px)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = enc.tower("siglip", px)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    px2 = px.flip(0).contiguous()
+    want2 = enc.tower("siglip", px2).clone()
+    px.copy_(px2)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want2)
+
+
 def test_tower_drops_trailing_pixels_like_valid_conv():
     """384 = 27*14 + 6: the stride-14 'valid' patch conv ignores the last 6 rows/cols (HF SiglipVisionEmbeddings)."""
     import tdc_video_amd  # noqa: F401
