@@ -10,12 +10,13 @@ namespace {
 std::mutex g_mu;
 std::vector<hipEvent_t> g_ev;        // 2 per record
 std::vector<tdc_prof_rec> g_rec;
-int g_n = 0, g_cap = 0, g_tag = 0;
+int g_n = 0, g_cap = 0, g_tag = 0, g_dropped = 0;   // g_dropped: launches that found the table full
 }  // namespace
 
 int tdc_prof_begin(int kind, hipStream_t st, int M, int N, int K, int act, int res, int out_f32, const void* W, double flops) {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (!tdc_prof_on || g_n >= g_cap) return -1;
+    if (!tdc_prof_on) return -1;
+    if (g_n >= g_cap) { ++g_dropped; return -1; }
     const int i = g_n++;
     tdc_prof_rec& r = g_rec[i];
     r.kind = kind; r.tag = g_tag; r.ms = 0.f; r.M = M; r.N = N; r.K = K; r.act = act; r.res = res; r.out_f32 = out_f32;
@@ -38,7 +39,7 @@ extern "C" int tdc_profile_start(int max_records) {
         g_ev.push_back(e);
     }
     g_rec.assign(max_records, tdc_prof_rec());
-    g_cap = max_records; g_n = 0; g_tag = 0;
+    g_cap = max_records; g_n = 0; g_tag = 0; g_dropped = 0;
     tdc_prof_on = 1;
     return 0;
 }
@@ -62,7 +63,7 @@ extern "C" int tdc_profile_stop(tdc_prof_rec* recs, int cap) {
         g_rec[i].ms = ms;
         if (recs) recs[i] = g_rec[i];
     }
-    const int total = g_n;
-    g_n = 0;
-    return total;       // > cap: the table the caller passed was too small (records beyond cap are dropped)
+    const int total = g_n + g_dropped;
+    g_n = 0; g_dropped = 0;
+    return total;       // > cap: a table (the caller's, or the one sized by tdc_profile_start) was too small - launches were dropped
 }
