@@ -182,26 +182,38 @@ def cpu_baseline(sd_cpu, cfg, H, K, px_s, px_d):
                        % (cores, n_v, t_v, runs[0], runs[2], t_c))
 
 
-def self_launch(n):
+def self_launch(n, guard_s=480.0, cmd=None):
     """`python bench.py --gpus N` without a launcher (the reference's eval drivers start one worker per GPU the same way,
     /root/reference/eval/eval_mlvu.py:129-157): N fresh child processes of this script, one per GPU, with
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set; rank 0's stdout (the JSON line) is this process's stdout,
     the other ranks' stdout goes to stderr.  Returns the worst child return code; when one child fails the others are
-    terminated (a failed rank is never restarted in place)."""
+    terminated (a failed rank is never restarted in place - a child that has touched the GPU is never re-exec'd).
+    guard_s: wall-clock guard (`--launch-timeout`).  A rank stuck in a collective must not hold the caller's GPU lease for
+    hours (the reference's own 8-hour NCCL timeout, tdc/train.py:892, is the anti-pattern): when the guard expires every live
+    child is terminated (then killed) and the launcher returns 124, printing no JSON line of its own.
+    cmd: the child command line (default: this script with this process's arguments; tests pass a stand-in)."""
     import socket
     import subprocess
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    if cmd is None:
+        cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else sys.stderr))
+        if os.environ.get("TDC_BENCH_CU_SPLIT") and n == 2:
+            # experiment hook (never set by the driver; tools/half_chip_gate.sh): both ranks on ONE GPU, each confined to half
+            # of the CUs of every XCD (mask bit i = XCD i % 8, CU slot i / 8: every XCD keeps 16 CUs per rank - a mask that
+            # empties an XCD would leave the workgroups dispatched to it without a CU).  Set before the child touches the GPU.
+            env["ROC_GLOBAL_CU_MASK"] = "0x" + ("f" * 32 if r == 0 else "f" * 32 + "0" * 32)
+            env["TDC_GEMM_PERSIST_GRID"] = "128"
+        procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else sys.stderr))
     worst = 0
     live = set(range(n))
+    t_end = time.monotonic() + guard_s if guard_s and guard_s > 0 else None
     while live:
         for r in sorted(live):
             rc = procs[r].poll()
@@ -213,13 +225,39 @@ def self_launch(n):
                 sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, rc))
                 for o in live:
                     procs[o].terminate()
+        if live and t_end is not None and time.monotonic() > t_end:
+            sys.stderr.write("bench.py: launch guard of %.0f s expired with rank(s) %s still running; stopping them\n"
+                             % (guard_s, sorted(live)))
+            for o in live:
+                procs[o].terminate()
+            worst = worst or 124
+            break
         time.sleep(0.05)
     for pr in procs:
         try:
             pr.wait(timeout=30)
         except subprocess.TimeoutExpired:
             pr.kill()
+            pr.wait()
     return worst
+
+
+def rank_guard(seconds):
+    """In-rank wall-clock guard (`--rank-timeout`): under a foreign launcher (torch.distributed.run) nothing else bounds a
+    rank that waits for a peer which never arrives.  A daemon timer; on expiry the rank says so on stderr and leaves with
+    code 124 (plain exit - never an exec - so the launcher sees a failed rank and stops the others)."""
+    import threading
+    if not seconds or seconds <= 0:
+        return None
+
+    def fire():
+        sys.stderr.write("bench.py: rank %s exceeded --rank-timeout %.0f s; exiting 124\n" % (os.environ.get("RANK", "0"), seconds))
+        sys.stderr.flush()
+        os._exit(124)
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
 
 
 def main():
@@ -256,13 +294,23 @@ def main():
                     "through DINOv2 instead of receiving its features point to point (fallback form of the boundary exchange)")
     ap.add_argument("--audio", action="store_true", help="BASELINE config 4: + T seconds of 16 kHz audio through BEATs "
                     "on the device, 50 audio tokens per frame in the Q-Former KV (1 GPU only)")
+    ap.add_argument("--launch-timeout", type=float, default=-1.0, help="N > 1 started as plain `python bench.py --gpus N`: wall-clock "
+                    "guard of the launcher in seconds; on expiry every rank is stopped and the exit code is 124 (0 = no guard; default "
+                    "600 + 4 x (steps + warmup))")
+    ap.add_argument("--rank-timeout", type=float, default=-1.0, help="wall-clock guard inside every rank in seconds (0 = none; "
+                    "default 600 + 4 x (steps + warmup): a step takes 1.2 s at T = 512 on one GPU)")
+    ap.add_argument("--collective-timeout", type=float, default=180.0, help="N > 1: timeout of the process group (rendezvous and "
+                    "every collective) in seconds")
     ap.add_argument("--dump-gemm-shapes", default=None, help="write the GEMM launches of one step (for tools/gemm_pmc)")
     args = ap.parse_args()
+    for k in ("launch_timeout", "rank_timeout"):
+        if getattr(args, k) < 0:
+            setattr(args, k, 600.0 + 4.0 * (args.steps + args.warmup))
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher.  Nothing above has touched the GPU (no torch.cuda call), and
         # nothing below this branch runs in this process.
-        sys.exit(self_launch(args.gpus))
+        sys.exit(self_launch(args.gpus, args.launch_timeout))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -273,15 +321,19 @@ def main():
     # swaps the transport, so the N>1 code path can be exercised on a 1-GPU box
     if os.environ.get("TDC_BENCH_ONE_GPU"):
         local = 0
+    guard = rank_guard(args.rank_timeout)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
+        import datetime
         import torch.distributed as dist
         backend = os.environ.get("TDC_DIST_BACKEND", "nccl")
+        # a bounded timeout on the rendezvous and on every collective: a rank that never arrives fails the job within minutes
+        tmo = datetime.timedelta(seconds=args.collective_timeout)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
     import tdc_video_amd  # noqa: F401
     from tdc_video_amd import ops
     from tdc_video_amd.pipeline import VideoEncoder
@@ -356,7 +408,14 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     rank_ms = None
+    ranks_seen = [0]
     if world > 1:
+        # who took part, as seen over the process group itself (RCCL at N > 1): every rank's id and device index
+        me = torch.tensor([rank, local], device=dev, dtype=torch.int64)
+        seen = [torch.zeros_like(me) for _ in range(world)]
+        torch.distributed.all_gather(seen, me)
+        ranks_seen = sorted(int(x[0].item()) for x in seen)
+        rank_devices = [int(x[1].item()) for x in sorted(seen, key=lambda x: int(x[0].item()))]
         # per-rank step times (a straggler shows as max >> min), then the MAX over the ranks as the job's time
         mine = torch.tensor([dt], device=dev, dtype=torch.float64)
         every = [torch.zeros_like(mine) for _ in range(world)]
@@ -485,6 +544,8 @@ def main():
                    "parallelism": "frames sharded over %d GPU(s)" % world, "two_streams": bool(two_streams),
                    "emitted_tokens": int(out.shape[0])},
         "rank_ms_per_step": None if rank_ms is None else {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
+        "ranks_seen": ranks_seen, "rank_devices": rank_devices if world > 1 else [local],
+        "dist_backend": (os.environ.get("TDC_DIST_BACKEND", "nccl") + " (RCCL)" * (os.environ.get("TDC_DIST_BACKEND", "nccl") == "nccl")) if world > 1 else None,
         "roofline": roofline,
     }
     if sd_cpu is not None:

@@ -1606,6 +1606,10 @@ inline int persistent_grid() {
             grid[dev] = 0;
         else
             grid[dev] = (prop.multiProcessorCount / 8) * 8;
+        // a process confined to part of the chip (ROC_GLOBAL_CU_MASK / HSA_CU_MASK: the device still reports every CU) says
+        // how many CUs it really owns - one persistent workgroup per CU, a multiple of 8 (the XCD arithmetic of the kernel)
+        const char* g = getenv("TDC_GEMM_PERSIST_GRID");
+        if (g && grid[dev] > 0 && atoi(g) >= 8 && atoi(g) <= grid[dev]) grid[dev] = (atoi(g) / 8) * 8;
         known[dev] = true;
     }
     return grid[dev];

@@ -51,3 +51,33 @@ def test_plain_python_bench_gpus2_on_one_gpu():
     rk = res["rank_ms_per_step"]
     assert len(rk["per_rank"]) == 2 and rk["max"] >= rk["min"] > 0
     assert res["roofline"]["frac"] > 0 and res["config"]["frames"] == 64
+    assert res["ranks_seen"] == [0, 1] and res["rank_devices"] == [0, 0] and res["dist_backend"] == "gloo"
+
+
+def test_launch_guard_stops_a_rank_that_never_finishes():
+    """One rank finishes, the other sleeps for ever (a peer stuck in a collective): the launcher must come back within its
+    wall-clock guard with code 124, having stopped the sleeper - not hold the caller's lease."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    child = [sys.executable, "-c", "import os, time\nif os.environ['RANK'] == '1':\n    time.sleep(10 ** 6)\n"]
+    t0 = time.monotonic()
+    rc = bench.self_launch(2, guard_s=3.0, cmd=child)
+    dt = time.monotonic() - t0
+    assert rc == 124
+    assert dt < 40, dt
+
+
+def test_launch_without_stragglers_is_unaffected_by_the_guard():
+    sys.path.insert(0, ROOT)
+    import bench
+    ok = [sys.executable, "-c", "import os; assert os.environ['WORLD_SIZE'] == '2' and os.environ['MASTER_ADDR'] == '127.0.0.1'"]
+    assert bench.self_launch(2, guard_s=60.0, cmd=ok) == 0
+    bad = [sys.executable, "-c", "import os, sys, time\nif os.environ['RANK'] == '0':\n    sys.exit(7)\ntime.sleep(10 ** 6)\n"]
+    assert bench.self_launch(2, guard_s=60.0, cmd=bad) == 7
+
+
+def test_rank_guard_ends_a_stuck_rank_with_124():
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; bench.rank_guard(1.0); time.sleep(60)" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=_env(), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 124 and "rank-timeout" in r.stderr
