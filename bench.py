@@ -182,6 +182,57 @@ def cpu_baseline(sd_cpu, cfg, H, K, px_s, px_d):
                        % (cores, n_v, t_v, runs[0], runs[2], t_c))
 
 
+def pmc_leg(gemms, budget_s, H, live_gemm_ms):
+    """The in-run counter leg (see the call site): -> (traffic bytes per launch, MFMA-busy fraction, MFMA-busy of the Q-Former's
+    stacked K/V GEMM, provenance string, full per-shape summary) or None when it could not run."""
+    import collections
+    import shutil
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_summary
+    binary = os.path.join(ROOT, "tools", "bin", "gemm_pmc")
+    t0 = time.monotonic()
+    if not os.path.exists(binary):          # normally built by __graft_entry__.build(); a 10-second hipcc job otherwise
+        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        if not os.path.exists(hipcc):
+            return None
+        os.makedirs(os.path.dirname(binary), exist_ok=True)
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-o", binary, os.path.join(ROOT, "tools", "gemm_pmc.cpp"),
+                            "-L" + os.path.join(ROOT, "tdc-video_amd"), "-ltdc_hip", "-Wl,-rpath," + os.path.join(ROOT, "tdc-video_amd")],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write("bench.py: building tools/bin/gemm_pmc failed: %s\n" % r.stderr[-300:])
+            return None
+    cnt = collections.Counter((r["M"], r["N"], r["K"], r["act"], r["res"], r["out_f32"]) for r in gemms)
+    shapes = [k + (c,) for k, c in sorted(cnt.items(), key=lambda kv: -kv[0][0] * kv[0][1] * kv[0][2] * kv[1])]
+    work = tempfile.mkdtemp(prefix="tdc_bench_pmc_")
+    try:
+        shapes_file = os.path.join(work, "shapes.txt")
+        with open(shapes_file, "w") as fh:
+            for sh in shapes:
+                fh.write("%d %d %d %d %d %d %d\n" % sh)
+        log = []
+        done = pmc_summary.collect(binary, shapes_file, work, reps=2, timeout_s=budget_s - (time.monotonic() - t0), log=log)
+        if "FETCH_SIZE" not in done or "WRITE_SIZE" not in done:
+            sys.stderr.write("bench.py: in-run counter leg incomplete (%s): %s\n" % (done, log[-1:] if log else "not started"))
+            return None
+        summ = pmc_summary.summarise(work, shapes, reps=2)
+    except Exception as e:  # noqa: BLE001
+        sys.stderr.write("bench.py: in-run counter leg failed: %r\n" % (e,))
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    kv = max((r.get("mfma_busy_frac", 0) for r in summ["shapes"] if r["N"] >= 9216 and r["K"] == H), default=None)
+    src = "measured in this run: %d rocprofv3 --pmc passes (one counter each: %s) over tools/bin/gemm_pmc, a torch-free replay of this " \
+          "run's %d GEMM launches (%d shapes, the second of two launches per shape) through the same libtdc_hip.so, started after " \
+          "the timed region; %.0f s" % (len(done), ", ".join(done), summ["launches_per_step"], len(shapes), time.monotonic() - t0)
+    if summ.get("gemm_ms_per_step_at_collection"):
+        src += "; live / replayed GEMM time per step = %.3f" % (live_gemm_ms / summ["gemm_ms_per_step_at_collection"])
+    summ["collected_by"] = "bench.py --pmc (in-run leg)"
+    return round(summ["per_launch_hbm_bytes"]), summ.get("mfma_busy_frac"), kv, src, summ
+
+
 def self_launch(n, guard_s=480.0, cmd=None):
     """`python bench.py --gpus N` without a launcher (the reference's eval drivers start one worker per GPU the same way,
     /root/reference/eval/eval_mlvu.py:129-157): N fresh child processes of this script, one per GPU, with
@@ -294,6 +345,11 @@ def main():
                     "through DINOv2 instead of receiving its features point to point (fallback form of the boundary exchange)")
     ap.add_argument("--audio", action="store_true", help="BASELINE config 4: + T seconds of 16 kHz audio through BEATs "
                     "on the device, 50 audio tokens per frame in the Q-Former KV (1 GPU only)")
+    ap.add_argument("--pmc", default="auto", choices=["auto", "on", "off"], help="N = 1: after the timed region collect FETCH_SIZE / "
+                    "WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE in fresh child processes (rocprofv3 --pmc over a torch-free "
+                    "replay of this run's GEMM launches) and report them as roofline.traffic / mfma_busy_pmc; auto = when rocprofv3 exists")
+    ap.add_argument("--pmc-budget", type=float, default=90.0, help="wall-clock budget of that leg in seconds")
+    ap.add_argument("--pmc-out", default="", help="write the leg's per-shape summary (JSON) to this file")
     ap.add_argument("--launch-timeout", type=float, default=-1.0, help="N > 1 started as plain `python bench.py --gpus N`: wall-clock "
                     "guard of the launcher in seconds; on expiry every rank is stopped and the exit code is 124 (0 = no guard; default "
                     "600 + 4 x (steps + warmup))")
@@ -474,25 +530,31 @@ def main():
     for r in xb:
         xb_kinds[r["kind"]] = round(xb_kinds.get(r["kind"], 0.0) + r["ms"], 3)
     xb_tf = xb_fl / (xb_ms * 1e-3) / 1e12 if xb_ms > 0 else None
-    # HBM-side traffic per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction).  They cannot be
-    # collected inside this process (rocprofv3 --pmc segfaults in a torch process on this image), so they come from a
-    # committed summary that the torch-free replay tools/gemm_pmc.cpp produced on this bench's own GEMM launch list
-    # (tools/run_gemm_pmc.sh).  The summary names the command line and the commit it was collected at; it is used only
-    # when this run's arguments match that command line, and the line says where the numbers come from - otherwise null.
+    # HBM-side traffic per launch and MFMA-pipe occupancy from the PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, gfx950 correction;
+    # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles)).  rocprofv3's counter collection cannot run inside this (torch)
+    # process on this image, so rank 0 at N = 1 starts FRESH child processes after the timed region: one rocprofv3 --pmc pass per
+    # counter over tools/bin/gemm_pmc, a torch-free program that replays THIS run's GEMM launch list through the same
+    # libtdc_hip.so (pmc_leg).  When that leg is unavailable (no rocprofv3, budget spent, N > 1, fp8) the numbers fall back to
+    # the committed summary of the same measurement - only when this run's arguments match it - and `traffic_source` says which.
     traffic = mfma_busy = kv_busy = traffic_source = None
+    pmc_shapes = None
+    if rank == 0 and world == 1 and args.pmc != "off" and args.dtype != "fp8":
+        got = pmc_leg(gemms, args.pmc_budget, H, g_ms)
+        if got is not None:
+            traffic, mfma_busy, kv_busy, traffic_source, pmc_shapes = got
     pmc = os.path.join(ROOT, "profiles", PMC_SUMMARY)
-    if os.path.exists(pmc):
+    if traffic is None and os.path.exists(pmc):
         summ = json.load(open(pmc))
         if summ.get("bench_args") == this_args:
             traffic = round(summ["per_launch_hbm_bytes"])
-            # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles) over the same launch list: MFMA pipe occupancy at the
-            # clock the chip actually holds (it drops to ~1.9 GHz under this load, so this reads higher than `frac`)
             mfma_busy = summ.get("mfma_busy_frac")
             kv_busy = max((r.get("mfma_busy_frac", 0) for r in summ["shapes"] if r["N"] >= 9216 and r["K"] == H), default=None)
             traffic_source = "replayed, not measured in this run: profiles/%s (tools/gemm_pmc.cpp on this launch list, " \
                              "collected at commit %s)" % (PMC_SUMMARY, summ.get("collected_at_commit", "?"))
             if summ.get("gemm_ms_per_step_at_collection"):   # staleness check: this run's GEMM time / the replayed run's
                 traffic_source += "; live / replayed GEMM time per step = %.3f" % (g_ms / summ["gemm_ms_per_step_at_collection"])
+    if args.pmc_out and pmc_shapes is not None and rank == 0:
+        json.dump(pmc_shapes, open(args.pmc_out, "w"), indent=1)
     # fp8 runs: the dense f8f6f4 MFMA peak (5 PFLOP/s) when every tower GEMM runs on e4m3 operands (level 2); at level 1
     # a third of the GEMM FLOPs stay in bf16, the bf16 peak is kept as the (conservative) yardstick
     peak = 2.0 * MFMA_PEAK_TFLOPS if (args.dtype == "fp8" and args.fp8_level >= 2) else MFMA_PEAK_TFLOPS
@@ -541,6 +603,11 @@ def main():
                                % (T, px_s, px_d, H, K, ", + %d s of 16 kHz audio through BEATs (50 audio tokens / frame in "
                                   "the Q-Former KV)" % T if args.audio else ""),
                    "frames": T, "K": K, "hidden": H, "px": px_s, "tower_residual": args.res if args.dtype != "fp8" else "fp32",
+                   # the model-level settings (tdc-video_amd/model.py: CambrianMetaModel.tdc_engine) that build this encoder
+                   "product_setting": {"dtype": str(dtype).replace("torch.", ""), "tdc_tower_dtype": str(tower_dtype).replace("torch.", ""),
+                                       "tdc_tower_res_dtype": "float16" if (args.res == "fp16" and args.dtype != "fp8") else "float32",
+                                       "tdc_tower_batch": args.tower_batch,
+                                       "tdc_fp8_towers": args.fp8_level if args.dtype == "fp8" else 0},
                    "parallelism": "frames sharded over %d GPU(s)" % world, "two_streams": bool(two_streams),
                    "emitted_tokens": int(out.shape[0])},
         "rank_ms_per_step": None if rank_ms is None else {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},

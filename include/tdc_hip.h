@@ -146,8 +146,8 @@ typedef struct {
 } tdc_attn_desc;
 #define TDC_ATTN_FORM_AUTO 0
 #define TDC_ATTN_FORM_16X16 1
-#define TDC_ATTN_FORM_PW 2    /* the one-wave-per-SIMD software-pipelined kernel (head dim 64, sq >= 256, sk >= 192; measured slower than
-                                 the AUTO choice, kept as a tested alternative), else as AUTO */
+/* (round 4's TDC_ATTN_FORM_PW = 2, a slower one-wave-per-SIMD prototype, left the library in round 5: any other value = AUTO;
+ *  the prototype lives in tools/attention_pw/) */
 int tdc_attention(const tdc_attn_desc* d, void* stream);
 
 /* ---- small data-movement / reduction kernels ------------------------------------------------------------- */

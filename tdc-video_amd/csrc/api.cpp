@@ -1,6 +1,7 @@
 // Composite entry points of the C ABI: whole-stage launch sequences over the primitive kernels (no Python between the
 // launches; graph-capturable: nothing here allocates or synchronises).
 #include "../../include/tdc_hip.h"
+#include "profile.h"
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
@@ -235,7 +236,8 @@ extern "C" int tdc_qformer_fwd(const tdc_qformer_model* m, const void* enc, int 
     }
     const int mode = qf_mode(m, K, Nenc);
     const bool fused = mode == 2;
-    tdc_profile_tag(TDC_PROF_TAG_XATTN_BLOCK);          // the cross-attention block's launches, for tdc_profile_*
+    {
+    TdcProfTagGuard tag_kv(TDC_PROF_TAG_XATTN_BLOCK);   // the cross-attention block's launches, for tdc_profile_*
     if (fused) {
         // keys of all cross layers: one GEMM; values of all cross layers TRANSPOSED: one GEMM with the operands swapped
         // (A = Wv [n_cross*dim, H], "weight" = enc [F*Nenc, H]) - vt[c][f*Nenc + key], the A operand of the PV product
@@ -250,7 +252,7 @@ extern "C" int tdc_qformer_fwd(const tdc_qformer_model* m, const void* enc, int 
         RET_IF(gemm_full(enc, ldenc, m->cross_kv, kv, m->cross_kv.n, F * Nenc, dt, TDC_ACT_NONE, 0, nullptr, 0, 0, ident,
                          ident, ident, stream));
     }
-    tdc_profile_tag(0);
+    }
     const float scale = (float)(1.0 / sqrt((double)hd));          // float(hd ** -0.5), correctly rounded (1.0f / sqrtf is 1 ulp off at 72, 96)
     for (int l = 0; l < m->n_layers; ++l) {
         const tdc_qformer_layer& L = m->layers_host[l];
@@ -267,7 +269,8 @@ extern "C" int tdc_qformer_fwd(const tdc_qformer_model* m, const void* enc, int 
         RET_IF(gemm_full(ctx, Dp, L.attn_out, t32, Dp, rows, dt, TDC_ACT_NONE, 1, h32, Dp, 1, ident, ident, ident,
                          stream));
         RET_IF(ln_map(t32, Dp, h16, h32, Dp, L.attn_ln_g, L.attn_ln_b, m->eps, rows, D, dt, ident, stream));
-        if (L.has_cross) tdc_profile_tag(TDC_PROF_TAG_XATTN_BLOCK);
+        {
+        TdcProfTagGuard tag_x(L.has_cross ? TDC_PROF_TAG_XATTN_BLOCK : -1);
         if (L.has_cross && fused) {
             tdc_xattn_desc x;
             memset(&x, 0, sizeof(x));
@@ -307,7 +310,7 @@ extern "C" int tdc_qformer_fwd(const tdc_qformer_model* m, const void* enc, int 
                 RET_IF(ln_map(t32, Dp, h16, h32, Dp, L.cross_ln_g, L.cross_ln_b, m->eps, F * K, D, dt, qmap, stream));
             }
         }
-        tdc_profile_tag(0);
+        }
         RET_IF(gemm_full(h16, Dp, L.fq1, mq, L.fq2.k, F * K, dt, TDC_ACT_GELU_ERF, 0, nullptr, 0, 0, qmap, ident, ident,
                          stream));
         if (q16)

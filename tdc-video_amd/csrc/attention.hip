@@ -399,10 +399,6 @@ extern "C" int tdc_attention(const tdc_attn_desc* d, void* stream) {
     if (d->dtype != TDC_F16 && d->dtype != TDC_BF16) return TDC_E_BADARG;
     TdcProfScope prof(TDC_PROF_ATTN, st, d->batch * d->heads, d->sq, d->sk, d->head_dim, 0, 0, nullptr,
                       4.0 * d->batch * d->heads * (double)d->sq * d->sk * d->head_dim);
-    if (d->form == TDC_ATTN_FORM_PW) {      // the one-wave-per-SIMD pipelined form, where it applies (on request only: it is slower)
-        const int rc = tdc_attention_pw(a, d->batch, d->dtype, st);
-        if (rc != -1) return rc;
-    }
     if (d->form != TDC_ATTN_FORM_16X16) {   // long sequences at head dim 64 / 72 (the towers): the 32x32x16 form
         const int rc = tdc_attention32(a, d->batch, d->dtype, st);
         if (rc != -1) return rc;

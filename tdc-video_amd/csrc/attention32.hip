@@ -57,7 +57,12 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(AttnArgs p) {
     typedef typename VecOf<T>::v4 v4;
     constexpr int KS = DK / 16;                              // k-steps of the QK^T product
     constexpr int NCH = DK / 8;                              // real 16-B chunks per K row
-    constexpr int KCH = (NCH <= 8) ? 8 : 16;                 // chunks per K row in LDS (128- or 256-byte rows)
+    // chunks per K row in LDS: 8 (128-byte rows, XOR swizzle) at head dim 64; at head dim 72 an ODD number of chunks (11 = 176-byte
+    // rows, no swizzle): the 16 lanes a ds_read_b128 cycle serves hold 16 keys that are distinct mod 16, and 11 key mod 16 is a
+    // permutation, so they hit 16 distinct 16-byte slots - and the staging writes (consecutive lanes = consecutive chunks of
+    // consecutive keys) wrap onto an occupied slot once per 16 lanes instead of six times as with round 4's 256-byte rows, where
+    // every row started on bank 0 (the d = 72 launches' 3.5 M conflict cycles, profiles/r04_attention_pmc_summary.txt)
+    constexpr int KCH = (NCH <= 8) ? 8 : (NCH | 1);
     constexpr int KROW = KCH * 8;
     constexpr int VCH = NDB * 4;                             // 16-B chunks per V row (64 B per output block)
     constexpr int VROW = VCH * 8;                            // d = 64: 128-byte rows, swizzled; d = 72: 192-byte rows
@@ -130,11 +135,11 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(AttnArgs p) {
             vreg[i] = load8(V + (long long)kr * p.v_rs, c * 8);
         }
     };
-    // K: physical chunk = chunk ^ f(key): 128-byte rows f = (key >> 1) & 7, 256-byte rows f = key & 15 - the 16 lanes one
-    // ds_read_b128 cycle serves ({0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} of each half) then hit 16 distinct 16-byte slots.
+    // K, 128-byte rows: physical chunk = chunk ^ ((key >> 1) & 7) - the 16 lanes one ds_read_b128 cycle serves ({0-3, 12-15,
+    // 20-27} / {4-11, 16-19, 28-31} of each half) then hit 16 distinct 16-byte slots; 176-byte rows do that by their stride.
     // V: 128-byte rows (d = 64): the 64-byte half is XORed with (key >> 1) & 1 so that the four keys of one transposed read
     // fall on four different 64-byte bank groups; 192-byte rows (3 output blocks) do that by their stride.
-    auto kswz = [](int key, int c) { return KCH == 8 ? (c ^ ((key >> 1) & 7)) : (c ^ (key & 15)); };
+    auto kswz = [](int key, int c) { return KCH == 8 ? (c ^ ((key >> 1) & 7)) : c; };
     auto vswz = [](int key, int c) { return NDB == 2 ? (c ^ (((key >> 1) & 1) << 2)) : c; };
     auto write_lds = [&](int buf) {
         T* kd = Ks + buf * (KT32 * KROW);
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(AttnArgs p) {
 
 template <class T, int DK, int NDB, int QB>
 int launch32(const AttnArgs& a, int batch, hipStream_t st) {
-    constexpr int KCH = (DK / 8 <= 8) ? 8 : 16;
+    constexpr int KCH = (DK / 8 <= 8) ? 8 : ((DK / 8) | 1);
     constexpr int lds = 2 * KT32 * (KCH * 8 + NDB * 32) * 2;
     static bool attr_dev[64];
     int dev = 0;

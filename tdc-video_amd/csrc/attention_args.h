@@ -20,5 +20,3 @@ struct AttnArgs {
 
 // attention32.hip: returns -1 when the 32x32 form does not apply (bias, short sequences, other head dims)
 int tdc_attention32(const AttnArgs& a, int batch, int dtype, hipStream_t st);
-// attention_pw.hip: the one-wave-per-SIMD, software-pipelined form (head dim 64 towers); -1 when it does not apply
-int tdc_attention_pw(const AttnArgs& a, int batch, int dtype, hipStream_t st);

@@ -70,20 +70,28 @@ extern "C" int tdc_gemm(const tdc_gemm_desc* d, void* stream) {
         if (d->c16_dtype_p1 < 1 || d->c16_dtype_p1 > 2 || d->out_f32 || d->act != TDC_ACT_NONE || d->x16 || d->ln_stats ||
             d->in_fp8 || d->out_fp8 || d->c_pad8)
             return TDC_E_BADARG;
+        /* the epilogues without a residual store C in the operand type: a C of the OTHER 16-bit type exists only on the
+           residual paths (the towers' 16-bit stream) - refuse instead of writing `dtype` bit patterns into such a buffer */
+        if (d->c16_dtype_p1 - 1 != d->dtype && !d->res) {
+            fprintf(stderr, "[tdc_hip] tdc_gemm: c16_dtype_p1 names the other 16-bit type but there is no residual (M=%d N=%d K=%d)\n",
+                    d->M, d->N, d->K);
+            return TDC_E_BADARG;
+        }
     }
     hipStream_t st = (hipStream_t)stream;
-#ifndef TDC_GEMM_DIAG
-    TdcProfScope prof(TDC_PROF_GEMM, st, d->M, d->N, d->K, d->act, d->res ? (d->res_f32 ? 1 : 2) : 0, d->out_f32, d->W,
-                      2.0 * d->M * d->N * d->K);
-#endif
     if (d->out_fp8) {    /* e4m3 output: fp8 operands with their scales, whole 64-column wave tiles, 16-byte rows */
         if (!d->in_fp8 || !d->ln_stats || !d->out_stats || d->out_f32 || d->res || d->c_map.seg != 0 || d->N % 64 != 0 ||
             (d->ldc & 15) || d->ldc < (d->act == TDC_ACT_SWIGLU ? d->N / 2 : d->N) || ((uintptr_t)d->C & 15) ||
             ((uintptr_t)d->out_stats & 7) || !(d->out_w2max > 0.f))
             return TDC_E_BADARG;
     }
+    if (!d->in_fp8 && d->dtype != TDC_F16 && d->dtype != TDC_BF16) return TDC_E_BADARG;
+    /* every argument check is behind us: a refused launch leaves no profiler record */
+#ifndef TDC_GEMM_DIAG
+    TdcProfScope prof(TDC_PROF_GEMM, st, d->M, d->N, d->K, d->act, d->res ? (d->res_f32 ? 1 : 2) : 0, d->out_f32, d->W,
+                      2.0 * d->M * d->N * d->K);
+#endif
     if (d->in_fp8) return tdc_gemm_fp8_impl(d, st);
-    if (d->dtype != TDC_F16 && d->dtype != TDC_BF16) return TDC_E_BADARG;
     // (Round 3 tried sending the last 128 columns of an N = 256 t + 128 GEMM - SigLIP's 1152-wide out-projection and fc2, whose
     // fifth column tile is half empty - to the 128 x 128 kernel as a launch of its own: 7-10 % SLOWER on both shapes; the second
     // launch streams the whole A operand again for an eighth of the columns.  Removed.)

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include <mutex>
+#include <unordered_map>
 
 // Diagnostic switch of the epilogue (timing experiments only), set through tdc_gemm_set_debug() - never from the
 // environment, so a stale variable cannot silently change what the production library computes.  Defined in gemm.hip.
@@ -107,47 +108,48 @@ constexpr bool kScaleOnly = false;
 
 template <int MI, int NJ, bool LANE, bool FOLD>
 struct EpiOps {
+    static constexpr bool kFold = FOLD;
     f32x4 bias[NJ], c1[NJ];
     float mean[MI], rstd[MI];
     __device__ __forceinline__ void load(const GemmArgs& p, int mbase, int nbase, int fr, int g, const EpiLane& el) {
+        if (!FOLD) return;          // the bias went into the accumulators before the first MFMA (acc_init_bias)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             if (LANE) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     bias[j][e] = lane_get(el.bias, j * 16 + g * 4 + e);
-                    if (FOLD && !kScaleOnly) c1[j][e] = lane_get(el.c1, j * 16 + g * 4 + e);
+                    if (!kScaleOnly) c1[j][e] = lane_get(el.c1, j * 16 + g * 4 + e);
                 }
             } else {
                 const int n = nbase + j * 16 + g * 4;
                 bias[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (FOLD) c1[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                c1[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (n < p.N) {
                     if (p.bias) bias[j] = *(const f32x4*)(p.bias + n);
-                    if (FOLD && !kScaleOnly) c1[j] = *(const f32x4*)(p.ln_c1 + n);
+                    if (!kScaleOnly) c1[j] = *(const f32x4*)(p.ln_c1 + n);
                 }
             }
         }
-        if (FOLD) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                if (LANE) {
-                    const int r = (i & 3) * 16 + fr;
-                    mean[i] = lane_get(i < 4 ? el.mean0 : el.mean1, r);
-                    rstd[i] = lane_get(i < 4 ? el.rstd0 : el.rstd1, r);
-                } else {
-                    int m = mbase + i * 16 + fr;
-                    if (m > p.M - 1) m = p.M - 1;
-                    const float2 st = *(const float2*)(p.ln_stats + 2 * (long long)m);
-                    mean[i] = st.x; rstd[i] = st.y;
-                }
+        for (int i = 0; i < MI; ++i) {
+            if (LANE) {
+                const int r = (i & 3) * 16 + fr;
+                mean[i] = lane_get(i < 4 ? el.mean0 : el.mean1, r);
+                rstd[i] = lane_get(i < 4 ? el.rstd0 : el.rstd1, r);
+            } else {
+                int m = mbase + i * 16 + fr;
+                if (m > p.M - 1) m = p.M - 1;
+                const float2 st = *(const float2*)(p.ln_stats + 2 * (long long)m);
+                mean[i] = st.x; rstd[i] = st.y;
             }
         }
     }
-    // the linear output of accumulator tile (i, j).  FOLD: two explicit fmas per element - the same instruction sequence
-    // in every kernel and layout (a row must not depend on which kernel computed it)
+    // the linear output of accumulator tile (i, j).  Without the fold the accumulators started from the bias (below) and ARE
+    // the linear output.  FOLD: two explicit fmas per element - the same instruction sequence in every kernel and layout (a row
+    // must not depend on which kernel computed it)
     __device__ __forceinline__ f32x4 lin(f32x4 acc, int i, int j) const {
-        if (!FOLD) return acc + bias[j];
+        if (!FOLD) return acc;
         f32x4 r;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -156,6 +158,30 @@ struct EpiOps {
         return r;
     }
 };
+
+// ---- the bias is the accumulators' initial value -------------------------------------------------------------------------
+// C = A W^T + b with the fp32 accumulators of column n starting at b[n] instead of 0: the epilogue's 128 `acc + bias` adds per
+// lane and tile (and, in the persistent kernel, the 16 ds_bpermute that gathered the bias behind the main loop) are gone, at
+// the price of moving b[n] instead of 0 into the accumulators - the same number of moves.  EVERY kernel does this (a row must
+// not depend on the kernel that computed it); the LayerNorm-fold / fp8-scale forms (ln_stats != NULL) need the bare product
+// and start from 0, their bias enters in EpiOps::lin.  Lane (fr, g) holds columns nbase + 16 j + 4 g .. + 3 of tile (i, j).
+template <int NJ>
+__device__ __forceinline__ void bias_cols_load(f32x4 (&b)[NJ], const GemmArgs& p, int nbase, int g) {
+    const bool on = p.bias != nullptr && p.ln_stats == nullptr;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = nbase + j * 16 + g * 4;
+        b[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (on && n < p.N) b[j] = *(const f32x4*)(p.bias + n);
+    }
+}
+template <int MI, int NJ>
+__device__ __forceinline__ void acc_init_bias(f32x4 (&acc)[MI][NJ], const f32x4 (&b)[NJ]) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = b[j];
+}
 
 // ---- LayerNorm fusion, producer side: (mean, M2) of one row x 64-column slot --------------------------------------------
 // The fp32 residual-stream GEMMs (out-projection, fc2) also write the updated row as 16-bit (x16, the next GEMM's A
@@ -472,13 +498,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     }
 
     f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
+    {   // the accumulators start from the bias (acc_init_bias): its load is in flight beside the first staged tile
+        f32x4 bcol[4];
+        bias_cols_load<4>(bcol, p, n0 + wn_ * 64, g);
+        stage(0, 0);
+        acc_init_bias<4, 4>(acc, bcol);
+    }
     const int nk = p.K / BK;
-    stage(0, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
@@ -520,14 +546,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     epilogue<T, 4, 4>(p, acc, m0 + wm * 64, n0 + wn_ * 64, fr, g);
 }
 
-// The staged epilogues carry an interior-tile fast path beside their general form.  Both need `ops.lin(acc[i][j])`; the same
-// expression on both sides of a branch is hoisted above it - here above the whole run-time dispatch of epilogue variants -
-// into NEW registers: 128 more live values next to the 128 accumulators (measured: 300-600 spilled VGPRs).  The fast paths
-// therefore work on an opaque copy of the (16-register) column operands, which makes their arithmetic theirs alone.
+// The staged epilogues carry an interior-tile fast path beside their general form.  With the LayerNorm fold both need
+// `ops.lin(acc[i][j])`; the same expression on both sides of a branch is hoisted above it - here above the whole run-time
+// dispatch of epilogue variants - into NEW registers: 128 more live values next to the 128 accumulators (measured: 300-600
+// spilled VGPRs).  The fast paths therefore work on an opaque copy of the (16-register) column operands, which makes their
+// arithmetic theirs alone.  Without the fold lin() is the identity (the bias is in the accumulators) and there is nothing to
+// hoist - making the ACCUMULATORS opaque instead was tried and spills 1400-5200 registers.
 template <class OPS>
 __device__ __forceinline__ OPS opaque_ops(OPS o) {
+    if (OPS::kFold) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(o.bias[j]));
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(o.bias[j]));
+    }
     return o;
 }
 
@@ -922,6 +952,28 @@ __device__ __forceinline__ void epi_staged32(const GemmArgs& p, f32x4 (&acc)[8][
 #ifndef TDC_RMW16_RING
 #define TDC_RMW16_RING 8      // residual loads in flight per wave (of the 16 a 128 x 64 sub-tile needs)
 #endif
+// a += float(r[0..3]), b += float(r[4..7]) for eight 16-bit residual values.  fp16: one v_fma_mix_f32 per element (the
+// half of the packed register converted on the fly, x 1.0, + the fp32 sum) instead of a conversion per element and a packed
+// add per pair - 8 instead of 12 instructions per eight values, the same correctly rounded fp32 sum (the conversion is exact).
+template <class TC>
+__device__ __forceinline__ void res_add8(f32x4& a, f32x4& b, typename VecOf<TC>::v8 r) {
+    if constexpr (std::is_same<TC, f16>::value) {
+        const u32x4 w = __builtin_bit_cast(u32x4, r);
+        auto mix = [](unsigned h, float lo, float hi, float& xl, float& xh) {
+            asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(xl) : "v"(h), "v"(lo));
+            asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(xh) : "v"(h), "v"(hi));
+        };
+        float x[8];
+        mix(w[0], a[0], a[1], x[0], x[1]); mix(w[1], a[2], a[3], x[2], x[3]);
+        mix(w[2], b[0], b[1], x[4], x[5]); mix(w[3], b[2], b[3], x[6], x[7]);
+        a = (f32x4){x[0], x[1], x[2], x[3]};
+        b = (f32x4){x[4], x[5], x[6], x[7]};
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] += (float)r[e]; b[e] += (float)r[4 + e]; }
+    }
+}
+
 template <class TC, int ROWS, bool LB, int RING>
 __device__ __forceinline__ void epi_staged_rmw16(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase, int nbase,
                                                  int lane, const EpiLane& el) {
@@ -970,8 +1022,7 @@ __device__ __forceinline__ void epi_staged_rmw16(const GemmArgs& p, f32x4 (&acc)
                 const v8c rr = ring[u % RING];
                 if (u + RING < NU) { ring[u % RING] = *(const v8c*)rptr; rptr += rstep; }
                 f32x4 a = lo[q], b = hi[q];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { a[e] += (float)rr[e]; b[e] += (float)rr[4 + e]; }
+                res_add8<TC>(a, b, rr);
                 __builtin_nontemporal_store(pack8(a, b), (v8c*)cptr);
                 cptr += cstep;
             }
@@ -1007,8 +1058,7 @@ __device__ __forceinline__ void epi_staged_rmw16(const GemmArgs& p, f32x4 (&acc)
             f32x4 b = *(const f32x4*)(region + r * 256 + (((2 * ck + 1) ^ (r & 15)) << 4));
             const v8c x = rr[u % RING];
             if (u + RING < NU) rr[u % RING] = load_res(u + RING);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { a[e] += (float)x[e]; b[e] += (float)x[4 + e]; }
+            res_add8<TC>(a, b, x);
             const int m = mbase + pass * ROWS + r, n = nbase + ck * 8;
             if (m < p.M && n < p.N) __builtin_nontemporal_store(pack8(a, b), (v8c*)((TC*)p.C + p.cm(m) * p.ldc + n));
         }
@@ -1162,10 +1212,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     }
 
     f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 bcol[4];        // the accumulators start from the bias (acc_init_bias); loaded here, moved in behind the prologue's wait
+    bias_cols_load<4>(bcol, p, n0 + wn_ * 64, g);
     v8 fa[4][2], fb0[2][2], fb1[2][2];
 
     const int nk = p.K / 64;
@@ -1225,6 +1273,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    acc_init_bias<8, 4>(acc, bcol);     // (the bias load is older than every staged load the waits above retired)
     T2_BARRIER();
     TDC_STAMP(1);
     // stagger: waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in its MFMA cluster while its
@@ -1494,10 +1543,21 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
             tile_coords(id + G8, p.tiles_m, p.tiles_n, tm1, tn1, p.group_m);
             m1 = tm1 * 256; n1 = tn1 * 256;
         }
+        if (LNF) {        // the fold needs the bare product (EpiOps::lin)
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        } else {          // the accumulators start from the bias (acc_init_bias): gathered from the lane-held set parked in LDS
+            const float bl = el_park()->bias;
+            const int bg = fresh_lane() >> 4;
+            f32x4 bcol[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bcol[j][e] = lane_get(bl, j * 16 + bg * 4 + e);
+            acc_init_bias<8, 4>(acc, bcol);
+        }
         const bool wave_active = n0 + wn_ * 64 < p.N;
 #ifdef TDC_GEMM_DIAG
         if (p.stamps && threadIdx.x == 0) {
@@ -1622,11 +1682,17 @@ inline int persistent_grid() {
 // with the kernel's own id -> tile arithmetic and takes the height with the fewest panels: 1 (row-major) for <= 7 column tiles
 // (12.3 panels at 5 or 6 columns), 4 or 8 for the wide GEMMs.  PMC, fabric bytes / algorithmic bytes: see NOTES round 4.
 inline int choose_group_m(int tiles_m, int tiles_n) {
-    static int memo_m[32], memo_n[32], memo_g[32], memo_cnt = 0;      // (a handful of shapes per process)
-    static std::mutex memo_mu;                                         // tdc_gemm is called from several host threads (dist.py)
-    std::lock_guard<std::mutex> lock(memo_mu);
-    for (int i = 0; i < memo_cnt; ++i)
-        if (memo_m[i] == tiles_m && memo_n[i] == tiles_n) return memo_g[i];
+    // memo: a serving process sees new tiles_m values all the time (tail batches differ per video) - unbounded map, looked up
+    // under the lock, computed OUTSIDE it (tdc_gemm is called from several host threads, dist.py; two threads computing the
+    // same entry at once write the same value)
+    static std::unordered_map<unsigned long long, int> memo;
+    static std::mutex memo_mu;
+    const unsigned long long key = ((unsigned long long)(unsigned)tiles_m << 32) | (unsigned)tiles_n;
+    {
+        std::lock_guard<std::mutex> lock(memo_mu);
+        const auto it = memo.find(key);
+        if (it != memo.end()) return it->second;
+    }
     const int cand[4] = {4, 8, 1, 2};                                   // ties go to the earlier entry
     const long long n = (long long)tiles_m * tiles_n;
     const long long len = n / 8 < 32 * 256 ? n / 8 : 32 * 256;           // up to 256 rounds of XCD 0's chunk
@@ -1652,7 +1718,8 @@ inline int choose_group_m(int tiles_m, int tiles_n) {
         }
         if ((double)panels < best_cost * 0.95) { best_cost = (double)panels; best = G; }   // 5 % hysteresis towards the earlier entry
     }
-    if (memo_cnt < 32) { memo_m[memo_cnt] = tiles_m; memo_n[memo_cnt] = tiles_n; memo_g[memo_cnt] = best; ++memo_cnt; }
+    std::lock_guard<std::mutex> lock(memo_mu);
+    memo[key] = best;
     return best;
 }
 

@@ -4,7 +4,7 @@
 #include <mutex>
 #include <vector>
 
-int tdc_prof_on = 0;
+std::atomic<int> tdc_prof_on{0};
 
 namespace {
 std::mutex g_mu;
@@ -15,7 +15,7 @@ int g_n = 0, g_cap = 0, g_tag = 0, g_dropped = 0;   // g_dropped: launches that 
 
 int tdc_prof_begin(int kind, hipStream_t st, int M, int N, int K, int act, int res, int out_f32, const void* W, double flops) {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (!tdc_prof_on) return -1;
+    if (!tdc_prof_on.load()) return -1;
     if (g_n >= g_cap) { ++g_dropped; return -1; }
     const int i = g_n++;
     tdc_prof_rec& r = g_rec[i];
@@ -32,7 +32,7 @@ void tdc_prof_end(int idx, hipStream_t st) {
 
 extern "C" int tdc_profile_start(int max_records) {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (tdc_prof_on || max_records <= 0) return TDC_E_BADARG;
+    if (tdc_prof_on.load() || max_records <= 0) return TDC_E_BADARG;
     while ((int)g_ev.size() < 2 * max_records) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return TDC_E_BADARG;
@@ -53,7 +53,7 @@ extern "C" int tdc_profile_tag(int tag) {
 
 extern "C" int tdc_profile_stop(tdc_prof_rec* recs, int cap) {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (!tdc_prof_on) return TDC_E_BADARG;
+    if (!tdc_prof_on.load()) return TDC_E_BADARG;
     tdc_prof_on = 0;
     const int n = g_n < cap ? g_n : cap;
     for (int i = 0; i < n; ++i) {

@@ -352,7 +352,13 @@ class CambrianMetaModel:
         `config.tdc_fp8_towers = True` / 2 / 3 (not a reference key) selects e4m3 operands for the towers' qkv / fc1 GEMMs
         (2: out-proj / fc2 as well; 3: fc1 also writes the e4m3 MLP hidden itself; DESIGN.md §4c);
         `config.tdc_tower_dtype = "bfloat16" | "float16"` (not a reference key either) runs the two ViT towers in that type
-        under a connector / Q-Former in `dtype` (VideoEncoder.tower_dtype)."""
+        under a connector / Q-Former in `dtype` (VideoEncoder.tower_dtype);
+        `config.tdc_tower_res_dtype = "float16" (default) | "bfloat16" | "float32"`: the towers' residual stream in HBM
+        (VideoEncoder.tower_res_dtype).  fp16 is the reference's own arithmetic - its HF towers run under
+        torch_dtype=float16, tdc/builder.py:69 - and what bench.py measures; fp8 towers keep the fp32 stream;
+        `config.tdc_tower_batch` (default 64, the reference's own chunk, tdc/cambrian_arch.py:698-745): frames per tower batch.
+        bench.py's line is reproduced by dtype=float16, tdc_tower_dtype="bfloat16", tdc_tower_res_dtype="float16",
+        tdc_tower_batch=512 (its `product_setting` field says so)."""
         if self._tdc_encoder is None or refresh:
             cfg = {k: getattr(self.config, k) for k in dir(self.config)
                    if not k.startswith("_") and isinstance(getattr(self.config, k, None), (int, float, str, bool, list))}
@@ -363,10 +369,15 @@ class CambrianMetaModel:
                                              siglip_heads=towers[0].heads, dino_heads=towers[1].heads,
                                              qformer_heads=self._qformer_arch["heads"],
                                              fp8_towers=int(cfg.get("tdc_fp8_towers", 0) or 0),
-                                             tower_dtype={"bfloat16": torch.bfloat16, "bf16": torch.bfloat16,
-                                                          "float16": torch.float16, "fp16": torch.float16,
-                                                          None: None}[cfg.get("tdc_tower_dtype")])
+                                             tower_batch=int(cfg.get("tdc_tower_batch", 64) or 64),
+                                             tower_dtype=_DT16[cfg.get("tdc_tower_dtype")],
+                                             tower_res_dtype=None if int(cfg.get("tdc_fp8_towers", 0) or 0)
+                                             else _DT16[cfg.get("tdc_tower_res_dtype", "float16")])
         return self._tdc_encoder
+
+
+_DT16 = {"bfloat16": torch.bfloat16, "bf16": torch.bfloat16, "float16": torch.float16, "fp16": torch.float16,
+         "float32": None, "fp32": None, None: None}
 
 
 class CambrianMetaForCausalLM(ABC):

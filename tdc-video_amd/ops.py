@@ -139,6 +139,7 @@ def gemm(a, w, bias=None, act=L.ACT_NONE, res=None, out=None, out_f32=False, M=N
     if not fp8 and not out_f32 and out.dtype != out_dtype:
         # C (and a 16-bit res) of the other 16-bit type: tdc_gemm_desc.c16_dtype_p1 (an fp16 residual stream under bf16 operands)
         assert out.dtype in (torch.float16, torch.bfloat16) and act == L.ACT_NONE
+        assert res is not None, "a 16-bit output of the other 16-bit type exists only on the residual paths (tdc_gemm refuses it too)"
         d.c16_dtype_p1 = _dtcode(out.dtype) + 1
     d.A, d.lda = a.data_ptr(), a.stride(0)
     d.W, d.ldw = w.data_ptr(), w.stride(0)

@@ -146,7 +146,7 @@ def full_sd():
 
 
 @pytest.mark.parametrize("fuse", ["0", "1"])
-@pytest.mark.parametrize("dtype,tol", [(torch.float16, 8e-3), (torch.bfloat16, 6e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])    # measured 2.3-2.6e-3 / 1.8-2.3e-2 (DINOv2)
 def test_fullsize_towers_vs_oracle(full_sd, dtype, tol, fuse, monkeypatch):
     """SigLIP-so400m (27 x 1152, d_head 72) and DINOv2-giant (40 x 1536, SwiGLU, LayerScale) at full depth and width:
     2 frames, HIP vs the fp32 oracle.  Tolerances are relative to max|ref| of the tower output: the raw residual
@@ -337,7 +337,9 @@ def test_fullsize_ln_fusion_matches_layernorm_kernel(full_sd, dtype, tol, monkey
         del enc
         torch.cuda.empty_cache()
     for a, b in zip(outs["0"], outs["1"]):
-        assert ((a - b).abs().max() / a.abs().max()).item() < tol
+        d = ((a - b).abs().max() / a.abs().max()).item()
+        print("ln_fuse vs LayerNorm kernel %s: %.3e of max|ref|" % (dtype, d))
+        assert d < tol
 
 
 @pytest.mark.parametrize("level", [1, 2, 3])

@@ -8,9 +8,11 @@
 // three tiles at once: while the VALU works through the softmax of tile t, the matrix pipe runs QK^T of tile t+1 and PV of tile
 // t-1 - independent instruction streams of ONE wave, so an MFMA's 32 cycles are filled by the wave's own exponentials.
 //
-// STATUS (round 4): correct (tests/test_hip_ops.py::test_attention_pw_form) and SLOWER than attention32.hip on the tower shape
-// (B = 512, 24 heads, S = 730: 3.0-3.4 ms against 2.45-2.6 ms; S = 4096: 1.14-1.30 ms against 1.05-1.10 ms), so tdc_attention
-// selects it only on request (tdc_attn_desc.form = TDC_ATTN_FORM_PW).  What was measured on the way (NOTES.md, round 4):
+// STATUS: a PROTOTYPE outside the product library since round 5 (it was form 2 of tdc_attention in round 4).  Correct
+// (tools/debug_attn_pw.py checks it against the library's kernel and fp32 SDPA) and SLOWER than attention32.hip on the tower shape
+// (B = 512, 24 heads, S = 730: 3.0-3.4 ms against 2.45-2.6 ms; S = 4096: 1.14-1.30 ms against 1.05-1.10 ms).  Built by
+// tools/attention_pw/build.sh into its own libtdc_attn_pw.so (entry: tdc_attn_pw_run, below), with tools/audit_asm_reads.py
+// run on the generated code as part of that build.  What was measured on the way (NOTES.md, round 4):
 //  * MFMA stream + softmax alone - K / V fragments and tiles frozen - runs at 1 600 TFLOP/s equivalent: the exponentials DO hide
 //    under the wave's own MFMAs; MFMA stream + LDS-DMA + fragment reads without the softmax at ~1 300; all three together at
 //    600-720: with one wave per SIMD every LDS-DMA issue (50-250 cycles each, four per tile), every barrier skew and the whole
@@ -33,8 +35,8 @@
 // K / V tiles (64 keys) come by LDS-DMA (global_load_lds, 16 B per lane, no VGPR round trip) into 4-slot rings, requested two
 // iterations ahead, one raw barrier per tile behind a counted vmcnt; the XOR swizzles of the fragment reads are applied on the
 // DMA's per-lane SOURCE address (the LDS image is lane-linear).
-#include "common.h"
-#include "../../include/tdc_hip.h"
+#include "common.h"            // -I tdc-video_amd/csrc
+#include "tdc_hip.h"           // -I include
 #include "attention_args.h"
 #include <type_traits>
 
@@ -499,9 +501,28 @@ int launch_pw64(const AttnArgs& a, int batch, hipStream_t st) {
 
 }  // namespace
 
-// entry for attention.hip: -1 when this form does not apply
+// -1 when this form does not apply
 int tdc_attention_pw(const AttnArgs& a, int batch, int dtype, hipStream_t st) {
     if (a.bias || !a.vec_ok || a.sq < 256 || a.sk < 3 * PW_KT || a.d != 64) return -1;
     if ((a.k_rs & 7) || (a.v_rs & 7)) return -1;
     return dtype == TDC_F16 ? launch_pw64<f16>(a, batch, st) : launch_pw64<bf16>(a, batch, st);
+}
+
+// entry of the prototype library: the tdc_attn_desc of include/tdc_hip.h (no bias / mask), TDC_E_BADARG where the form does not apply
+extern "C" int tdc_attn_pw_run(const tdc_attn_desc* d, void* stream) {
+    if (!d || !d->q || !d->k || !d->v || !d->o || d->bias || d->key_mask || d->head_dim != 64) return TDC_E_BADARG;
+    if (d->dtype != TDC_F16 && d->dtype != TDC_BF16) return TDC_E_BADARG;
+    AttnArgs a;
+    a.q = d->q; a.k = d->k; a.v = d->v; a.o = d->o;
+    a.q_bs = d->q_bs; a.k_bs = d->k_bs; a.v_bs = d->v_bs; a.o_bs = d->o_bs;
+    a.q_rs = d->q_rs; a.k_rs = d->k_rs; a.v_rs = d->v_rs; a.o_rs = d->o_rs;
+    a.heads = d->heads; a.d = d->head_dim; a.sq = d->sq; a.sk = d->sk;
+    a.scale_log2 = d->scale * 1.4426950408889634f;
+    auto al = [](const void* p, int bytes) { return ((uintptr_t)p % bytes) == 0; };
+    a.vec_ok = (d->q_rs % 8 == 0) && (d->k_rs % 8 == 0) && (d->v_rs % 8 == 0) && (d->o_rs % 4 == 0) && (d->q_bs % 8 == 0) &&
+               (d->k_bs % 8 == 0) && (d->v_bs % 8 == 0) && (d->o_bs % 4 == 0) && al(d->q, 16) && al(d->k, 16) && al(d->v, 16) &&
+               al(d->o, 8);
+    a.bias = nullptr; a.bias_hs = 0; a.bias_rs = 0; a.gate = nullptr; a.gate_rs = 0; a.kmask = nullptr; a.kmask_bs = 0;
+    const int rc = tdc_attention_pw(a, d->batch, d->dtype, (hipStream_t)stream);
+    return rc == -1 ? TDC_E_BADARG : rc;
 }

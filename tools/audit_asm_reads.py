@@ -1,4 +1,4 @@
-"""Audit of csrc/attention_pw.hip's generated code (run on the .s of `hipcc --save-temps`): every ds_read_b64_tr_b16 issued from an
+"""Audit of tools/attention_pw/attention_pw.hip's generated code (run on the .s of `hipcc --save-temps`): every ds_read_b64_tr_b16 issued from an
 asm statement (the compiler does not count it) must be followed by an `s_waitcnt ... lgkmcnt(0)` before any instruction reads or
 overwrites its destination registers.  Prints the violations (none = exit 0)."""
 import re

@@ -25,15 +25,6 @@ def main():
                                           1 / math.sqrt(d), S * ld, S * ld, S * ld, S * out.stride(0), form=form)
         ms16 = timeit(lambda: fn(1))
         ms = timeit(fn)
-        if d == 64:
-            mspw = timeit(lambda: fn(2))
-            fn(2)
-            torch.cuda.synchronize()
-            qq, kk, vv = (qkv[: 2 * S, i * D:(i + 1) * D].float().view(2, S, H, d).transpose(1, 2) for i in range(3))
-            refpw = F.scaled_dot_product_attention(qq, kk, vv).transpose(1, 2).reshape(2 * S, D)
-            print("attn B=%d H=%d d=%d S=%d  pw form    %8.3f ms  %7.1f TFLOP/s | max err %.2e"
-                  % (B, H, d, S, mspw, 4.0 * B * H * S * S * d / mspw / 1e9, (out[: 2 * S, :D].float() - refpw).abs().max().item()), flush=True)
-            fn()
         q, k, v = (qkv[: 2 * S, i * D:(i + 1) * D].float().view(2, S, H, d).transpose(1, 2) for i in range(3))
         ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(2 * S, D)
         err = (out[: 2 * S, :D].float() - ref).abs().max().item()
