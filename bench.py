@@ -587,6 +587,11 @@ def main():
             tflops=MFMA_DENSE_SUSTAINED_TFLOPS, frac=round(achieved / MFMA_DENSE_SUSTAINED_TFLOPS, 4),
             note="replayed constant, not measured in this run: bf16 16x16x32 MFMAs on dense random register operands, no memory "
                  "traffic, every CU busy (tools/mfma_power.cpp, profiles/r02_mfma_power.log); all-zero operands reach 2448")
+    if world > 1:
+        # every rank is done with the process group: leave it in step (a rank that exits while a peer is still inside a
+        # collective shows up as a watchdog abort in that peer's log)
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
     if rank != 0:
         return
     res = {

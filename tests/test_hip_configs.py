@@ -131,7 +131,12 @@ def _full_depth_reference(px_s, px_d, T, H, K, mns):
     return _FULL_DEPTH_REF[key]
 
 
-STATIC_ATOL = {torch.float16: 2.5e-3, torch.bfloat16: 5e-3}      # provisional: set from the round-5 measurement
+# static rows element by element: |err| <= atol + rtol |ref| with rtol = 2^-10 (fp16 towers: half an fp16 ulp of the value) or 2^-9
+# (bf16 tower operands).  Measured (round 5, profiles/r05_config1_full_depth_test.log): the part of |err| the relative term does
+# not cover is 1.50e-3 with fp16 towers and 3.5-3.9e-3 with bf16 operands - on elements of small magnitude, i.e. accumulated
+# 16-bit error of the towers and the fp16 connector, not output rounding; the north_star's literal 1e-3 atol holds for the
+# unit-norm compressed tokens only (1.2e-4 measured), and these constants (<= 1.5 x measured) are what is claimed for static rows
+STATIC_ATOL = {torch.float16: 2.2e-3, torch.bfloat16: 5.5e-3}
 
 
 @pytest.mark.parametrize("tower_dtype,res_dtype,px", [                 # all at the BENCH's own geometry: 384 / 378 px, 27 x 27 -> 24 x 24
@@ -151,7 +156,8 @@ def test_config1_full_depth_end_to_end_vs_oracle(tower_dtype, res_dtype, px):
     through the whole composition; static rows (projector outputs of magnitude up to 4.1, where ONE fp16 ulp is 3.9e-3, so a
     literal 1e-3 atol is not something 16-bit outputs can meet - the reference's own fp16 inference included) in the form that
     IS claimable, element by element: |err| <= 1e-3 + 2^-10 |ref| with fp16 towers (half an fp16 ulp of the value on top of the
-    north_star's atol), <= 1e-3 + 2^-9 |ref| in the bench's type - and <= 7e-4 / 1.5e-3 of max|ref| as one number.
+    north_star's atol) was the hoped-for form and is NOT met: measured 1.5e-3 + 2^-10 |ref| with fp16 towers, 3.7e-3 + 2^-9 |ref|
+    in the bench's type (STATIC_ATOL above holds what is asserted) - and <= 7e-4 / 1.5e-3 of max|ref| as one number.
     tower_dtype = bfloat16 with res_dtype = float16 is the bench's type (bf16 GEMM operands in the towers, their residual
     stream in fp16, fp16 connector / Q-Former); the tower features themselves carry the bf16 error.  Bounds are <= 1.5 x what
     was measured (profiles/r05_config1_full_depth_test.log), so that a regression shows."""
@@ -318,7 +324,7 @@ def test_config5_llama_H3072_connector_compressor_vs_oracle():
     err_c = float((got[comp_rows].float().cpu() - want[comp_rows]).abs().max())
     err_s = _rel(got[stat_rows], want[stat_rows])
     print("H=3072: compressed-token max abs err %.3e, static rows rel %.3e" % (err_c, err_s))
-    assert err_c < 1e-3 and err_s < 4e-3, (err_c, err_s)
+    assert err_c < 1e-3 and err_s < 8e-4, (err_c, err_s)        # measured 1.0e-4 / 5.3e-4
 
 
 @pytest.mark.parametrize("level", [1])

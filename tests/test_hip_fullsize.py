@@ -214,7 +214,7 @@ def test_fullsize_connector_compressor_vs_oracle(full_sd):
     err_s = _rel(got[stat_rows], want[stat_rows])
     print("full-size compressed-token max abs err %.3e (unit-norm rows), static rows rel %.3e" % (err_c, err_s))
     assert err_c < 1e-3, err_c
-    assert err_s < 4e-3, err_s
+    assert err_s < 8e-4, err_s          # measured 4.7e-4
 
 
 def test_fullsize_video_plus_audio_token_accounting(full):
@@ -315,7 +315,7 @@ def test_config4_T512_with_512s_of_audio_properties():
     assert torch.equal(a[seps], enc.c.frame_seg[0, :H].to(a.dtype).expand(seps.numel(), H))
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float16, 8e-3), (torch.bfloat16, 6e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 4.5e-3), (torch.bfloat16, 3.7e-2)])     # measured 2.9e-3 / 2.4e-2 (DINOv2)
 def test_fullsize_ln_fusion_matches_layernorm_kernel(full_sd, dtype, tol, monkeypatch):
     """VideoEncoder(ln_fuse=True) (pre-LayerNorms folded into the neighbouring GEMMs: 16-bit row copy + per-slot statistics out of the
     residual-stream GEMM, (mean, rstd) folded into the next GEMM's epilogue) against the LayerNorm-kernel path, both

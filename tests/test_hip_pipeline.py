@@ -197,10 +197,12 @@ def test_siglip_tower_stress(mode, dtype, rdtype):
 
 # measured on the MI355X (round 5, printed by the test; bounds <= 1.5 x measured) - see the docstring for what each column is
 OUTLIER_TOL = {  # (operands, stream): (ordinary channels: of their own max|ref|, outlier channels: relative, DINOv2 similarities: abs)
-    (torch.float16, None): (2e-2, 2e-3, 1e-4),
-    (torch.float16, torch.float16): (2e-2, 4e-3, 1e-4),
-    (torch.bfloat16, None): (1.5e-1, 1.5e-2, 1e-3),
-    (torch.bfloat16, torch.float16): (1.5e-1, 1.5e-2, 1e-3),
+    # measured, SigLIP / DINOv2: fp16 over fp32 7.4e-4 / 5.2e-4, 3.3e-4 / 5.3e-4; fp16 over fp16 1.4e-3 / 5.2e-4, 8.8e-4 / 7.2e-4;
+    # bf16 operands (either stream) 3.7e-3 / 2.3e-3, 8.8e-4 / 3.5e-3; similarities 2.3e-5 everywhere
+    (torch.float16, None): (1.2e-3, 8e-4, 5e-5),
+    (torch.float16, torch.float16): (2.2e-3, 1.4e-3, 5e-5),
+    (torch.bfloat16, None): (5.6e-3, 5.3e-3, 5e-5),
+    (torch.bfloat16, torch.float16): (5.6e-3, 5.3e-3, 5e-5),
 }
 
 
@@ -217,7 +219,7 @@ def test_tower_outlier_channels(kind, tdtype, rdtype):
     stream); the C++ composite equals the per-kernel sequence bit for bit; the outlier channels relative to their own size; the
     ORDINARY channels relative to THEIR max|ref| (the outlier dominates every LayerNorm's statistics - ordinary channels leave
     the norm at ~1/600 of their size - and its rounding error in a 16-bit operand, 2^-11 or 2^-8 of ~30, rides on every GEMM
-    output: this is the number that shows what an outlier costs, and why it is bounded looser than the natural-scale tests);
+    output: this is the number that shows what an outlier costs; measured, it stays at the level of the natural-scale tests);
     for DINOv2 the adjacent-frame cosine similarities that decide the segment selection (a5)."""
     import tdc_video_amd  # noqa: F401
     from tdc_video_amd import weights as Wt
