@@ -1141,85 +1141,14 @@ constexpr int T2_HALF = 128 * 64 * 2;         // 16 KiB
 constexpr int T2_BUF = 4 * T2_HALF;           // A0 A1 W0 W1
 constexpr int T2_LDS = 2 * T2_BUF;            // 128 KiB
 
-#define T2_EPI_BARRIER() __builtin_amdgcn_s_barrier()
-template <class T, bool FP8>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
-    typedef typename VecOf<T>::v8 v8;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int id = xcd_remap(blockIdx.x, nwg);
-    int tm, tn;
-    tile_coords(id, p.tiles_m, p.tiles_n, tm, tn, p.group_m);
-    const int m0 = tm * 256, n0 = tn * 256;
-#ifdef TDC_GEMM_DIAG
-    if (p.stamps && threadIdx.x == 0) {
-        p.stamps[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_ID
-        p.stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg((3 << 11) | 20);     // XCC_ID
-    }
-#endif
-    TDC_STAMP(0);
-
-    // ---- staging sources: per half 2 glds per thread; instruction (wave*2 + j) covers half rows 8*(wave*2+j) .. +7
-    const int srow = lane >> 3;
-    const int schunk = (lane & 7) ^ srow;
-    const char* a_src[2][2];
-    const char* w_src[2][2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = (wave * 2 + j) * 8 + srow;                       // row within the half (0..127)
-            int am = m0 + (r >> 6) * 128 + h * 64 + (r & 63);
-            int wn = n0 + (r >> 5) * 64 + h * 32 + (r & 31);
-            if (am > p.M - 1) am = p.M - 1;
-            if (wn > p.N - 1) wn = p.N - 1;
-            a_src[h][j] = (const char*)p.A + (p.am(am) * (long long)p.lda + schunk * 8) * 2;
-            w_src[h][j] = (const char*)p.W + ((long long)wn * p.ldw + schunk * 8) * 2;
-        }
-    const int lds_stage = wave * 2 * 1024;
-    auto stage_a = [&](int buf, int h, int kt) {
-        char* dst = smem + buf * T2_BUF + h * T2_HALF + lds_stage;
-        const long long koff = (long long)kt * 128;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[h][0] + koff), LDS_PTR(dst), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[h][1] + koff), LDS_PTR(dst + 1024), 16, 0, 0);
-    };
-    auto stage_w = [&](int buf, int h, int kt) {
-        char* dst = smem + buf * T2_BUF + (2 + h) * T2_HALF + lds_stage;
-        const long long koff = (long long)kt * 128;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(w_src[h][0] + koff), LDS_PTR(dst), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(GLB_PTR(w_src[h][1] + koff), LDS_PTR(dst + 1024), 16, 0, 0);
-    };
-
-    // ---- fragment read offsets inside a half
-    // wave -> (row, column) of the 2 x 4 wave grid: the two waves of a SIMD (w and w+4) take wave columns c and c+2, so
-    // in a tile whose upper half of the columns lies beyond N (N = 1152: the 5th column tile) every SIMD keeps exactly one
-    // working wave and the idle partner's MFMA slots are not wasted
-    const int wm = (wave >> 1) & 1, wn_ = (wave & 1) | ((wave >> 2) << 1);
-    const bool wave_active = n0 + wn_ * 64 < p.N;   // wave-uniform: this wave owns at least one valid column
-    const int fr = lane & 15, g = lane >> 4;
-    int a_off[4], w_off[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = wm * 64 + i * 16 + fr;
-        a_off[i] = r * 128 + ((g ^ (r & 7)) << 4);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = wn_ * 32 + j * 16 + fr;
-        w_off[j] = r * 128 + ((g ^ (r & 7)) << 4);
-    }
-
-    f32x4 acc[8][4];
-    f32x4 bcol[4];        // the accumulators start from the bias (acc_init_bias); loaded here, moved in behind the prologue's wait
-    bias_cols_load<4>(bcol, p, n0 + wn_ * 64, g);
-    v8 fa[4][2], fb0[2][2], fb1[2][2];
-
-    const int nk = p.K / 64;
+// (Round 5 removed the one-tile-per-workgroup form of this kernel, `gemm256_kernel`: with the bias as the accumulators' initial
+// value its register allocation parked accumulator tiles in scratch INSIDE the K loop - every reload a vmcnt(0) that drains the
+// staging pipeline, the row-mapped Q-Former GEMMs ran 26-36 % slower - and four re-arrangements of its prologue did not move the
+// spills out again.  The persistent form below (0 spills) now takes every launch of 256 x 256 tiles: row-mapped A operands through
+// per-tile offsets, launches with fewer tiles than CUs as workgroups with one tile.)
 #define T2_BARRIER() __builtin_amdgcn_s_barrier()
-    // end of a load segment: retire this wave's LDS reads BEFORE the barrier (so that a later stage by any wave, incl.
-    // the other, staggered, wave group, can never overwrite bytes still being read), then pin the MFMA cluster below it
+// end of a load segment: retire this wave's LDS reads BEFORE the barrier (so that a later stage by any wave, incl.
+// the other, staggered, wave group, can never overwrite bytes still being read), then pin the MFMA cluster below it
 #define T2_END_LOADS()                                          \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          \
     __builtin_amdgcn_s_barrier();                               \
@@ -1261,87 +1190,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         __builtin_amdgcn_s_setprio(0);                                              \
     }
 
-    // The pipeline is instantiated twice: the working form, and a form for waves without a valid column that only stages
-    // and keeps the barriers (a run-time branch around the MFMA clusters inside ONE loop costs the working form ~5 %).
-    auto pipeline = [&](auto active_c) {
-    constexpr bool active = decltype(active_c)::value;
-    // ---- prologue: tile 0 complete + tile 1's A0 B0 B1
-    stage_a(0, 0, 0); stage_w(0, 0, 0); stage_w(0, 1, 0); stage_a(0, 1, 0);
-    if (nk > 1) {
-        stage_a(1, 0, 1); stage_w(1, 0, 1); stage_w(1, 1, 1);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    acc_init_bias<8, 4>(acc, bcol);     // (the bias load is older than every staged load the waits above retired)
-    T2_BARRIER();
-    TDC_STAMP(1);
-    // stagger: waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in its MFMA cluster while its
-    // partner is in its LDS-read / staging segment (MI355X_MICROARCH.md "Two waves per SIMD")
-    if (wave >= 4) T2_BARRIER();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1, nxt = cur ^ 1;
-        // ---- phase 1: quadrant (a0, b0)
-        T2_LOAD_B(fb0, cur, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        T2_LOAD_A(cur, 0);
-        if (kt + 1 < nk) stage_a(nxt, 1, kt + 1);
-        T2_END_LOADS();
-        T2_MMA(0, 0, fb0);
-        T2_BARRIER();
-        // ---- phase 2: quadrant (a0, b1)
-        T2_LOAD_B(fb1, cur, 1);
-        if (kt + 2 < nk) stage_a(cur, 0, kt + 2);
-        T2_END_LOADS();
-        T2_MMA(0, 2, fb1);
-        T2_BARRIER();
-        // ---- phase 3: quadrant (a1, b1)
-        T2_LOAD_A(cur, 1);
-        if (kt + 2 < nk) stage_w(cur, 0, kt + 2);
-        T2_END_LOADS();
-        T2_MMA(4, 2, fb1);
-        T2_BARRIER();
-        // ---- phase 4: quadrant (a1, b0); retire tile kt+1 (3 half-tiles of tile kt+2 may stay in flight)
-        if (kt + 2 < nk) {
-            stage_w(cur, 1, kt + 2);
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        T2_BARRIER();
-        __builtin_amdgcn_sched_barrier(0);
-        T2_MMA(4, 0, fb0);
-        T2_BARRIER();
-    }
-    if (wave < 4) T2_BARRIER();   // matches the stagger barrier of waves 4-7
-    };
-    if (wave_active) pipeline(std::true_type()); else pipeline(std::false_type());
-
-    // ---- epilogue: lane holds C[m = m0 + wm*128 + 16 i + fr][n = n0 + wn*64 + 16 j + 4g .. +3]
-    TDC_STAMP(2);
-    if (p.debug == 1) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
-        return;
-    }
-    if (p.debug != 2) {
-        T2_EPI_BARRIER();   // every wave is past its last LDS read: the pipeline buffers become staging space
-        if (!wave_active) return;
-        if (epilogue_staged<T, false>(p, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn_ * 64, lane)) {
-#ifdef TDC_GEMM_DIAG
-            TDC_STAMP(3);
-            if (p.debug == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            TDC_STAMP(4);
-#endif
-            return;
-        }
-    }
-    epilogue<T, 8, 4>(p, acc, m0 + wm * 128, n0 + wn_ * 64, fr, g);
-}
-
 // ======================================================================================================================
 // Persistent form of the 256^2 kernel: one workgroup per CU walks its tiles (static round-robin inside the XCD's contiguous
 // chunk of the grouped tile order, so the 32 workgroups of an XCD still cover the same patch of tiles at any time).
@@ -1351,7 +1199,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 // Here the staging stream simply runs on across the tile seam: the last two K iterations of a tile stage K tiles 0 and 1
 // of the NEXT tile (the staging cursor switches its base pointers between phase 1 and phase 2 of iteration nk-2), the
 // epilogue stages through 4 KiB per wave BESIDE the 128 KiB pipeline buffers, and the next main loop starts with its
-// operands already in LDS.  Staging addresses are an SGPR tile base + 32-bit per-lane offsets (a_map must be identity).
+// operands already in LDS.  Staging addresses are an SGPR tile base + 32-bit per-lane offsets (a row-mapped A: set_stage_tile).
 constexpr int T2P_LDS = T2_LDS + 8 * 4096;    // 160 KiB
 
 template <class T, bool LNF, bool FP8>  // LNF: LayerNorm-fold consumer (ln_stats != NULL): 5 more lane-held epilogue operands
@@ -1383,7 +1231,11 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
         const int sl = fresh_lane();
         const int srow = sl >> 3;
         const int schunk = (sl & 7) ^ srow;
-        a_base = (const char*)p.A + (long long)m0 * p.lda * 2;
+        // A rows through the row map (tdc_gemm_desc.a_map; host: monotone, a tile's rows within 2 GiB of its first one): the
+        // tile base is the mapped first row, the per-lane offsets the mapped rows relative to it
+        const bool mapped = p.am.seg != 0;                                     // uniform
+        const long long arow0 = mapped ? p.am(m0) : (long long)m0;
+        a_base = (const char*)p.A + arow0 * p.lda * 2;
         w_base = (const char*)p.W + (long long)n0 * p.ldw * 2;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -1394,6 +1246,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
                 int wn = (r >> 5) * 64 + h * 32 + (r & 31);
                 if (am > p.M - 1 - m0) am = p.M - 1 - m0;
                 if (wn > p.N - 1 - n0) wn = p.N - 1 - n0;
+                if (mapped) am = (int)(p.am(m0 + am) - arow0);
                 a_so[h][j] = (unsigned)(am * p.lda + schunk * 8) * 2u;
                 w_so[h][j] = (unsigned)(wn * p.ldw + schunk * 8) * 2u;
             }
@@ -1417,6 +1270,9 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
         __builtin_amdgcn_global_load_lds(GLB_PTR(src + w_so[h][1]), LDS_PTR(dst + 1024), 16, 0, 0);
     };
 
+    // wave -> (row, column) of the 2 x 4 wave grid: the two waves of a SIMD (w and w+4) take wave columns c and c+2, so
+    // in a tile whose upper half of the columns lies beyond N (N = 1152: the 5th column tile) every SIMD keeps exactly one
+    // working wave and the idle partner's MFMA slots are not wasted
     const int wm = (wave >> 1) & 1, wn_ = (wave & 1) | ((wave >> 2) << 1);
     const int fr = lane & 15, g = lane >> 4;
     int a_off[4], w_off[2];
@@ -1529,7 +1385,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     T2_BARRIER();
     for (int it = 0; it < n_my; ++it) {
-        // stagger (see gemm256_kernel), re-established for every tile: the two wave groups leave a tile's loop one barrier apart,
+        // stagger: waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in its MFMA cluster while its partner is
+        // in its LDS-read / staging segment (MI355X_MICROARCH.md "Two waves per SIMD").  Re-established for every tile: the two wave groups leave a tile's loop one barrier apart,
         // and a group's epilogue holds no barrier - left staggered, waves 4-7 would sit at their last barrier of the tile for the
         // whole length of waves 0-3's epilogue and waves 0-3 then at their first barrier of the next tile for the whole length of
         // waves 4-7's: the two halves of the C tile drained one after the other (per-wave stamps, tools/run_gemm_epi_parts.sh:
@@ -1680,7 +1537,7 @@ inline int persistent_grid() {
 // distinct tile rows + tile columns of a window of 32 ids.  With GROUP_M x tiles_n not a multiple of 32 the windows straddle
 // groups (N = 1152 at GROUP_M = 8: 17.4 panels per window on average instead of 12); the host walks the first windows of a chunk
 // with the kernel's own id -> tile arithmetic and takes the height with the fewest panels: 1 (row-major) for <= 7 column tiles
-// (12.3 panels at 5 or 6 columns), 4 or 8 for the wide GEMMs.  PMC, fabric bytes / algorithmic bytes: see NOTES round 4.
+// (12.3 panels at 5 or 6 columns), 4 or 8 for the wide GEMMs.  PMC, fabric bytes / algorithmic bytes: see profiles/archive/NOTES_rounds1-4.md 9.4.
 inline int choose_group_m(int tiles_m, int tiles_n) {
     // memo: a serving process sees new tiles_m values all the time (tail batches differ per video) - unbounded map, looked up
     // under the lock, computed OUTSIDE it (tdc_gemm is called from several host threads, dist.py; two threads computing the
@@ -1769,34 +1626,36 @@ int launch(const tdc_gemm_desc* d, hipStream_t st, bool force128 = false) {
     a.am = RowMap::make(d->a_map.seg, d->a_map.stride, d->a_map.off, d->a_map.inner);
     a.cm = RowMap::make(d->c_map.seg, d->c_map.stride, d->c_map.off, d->c_map.inner);
     a.rm = RowMap::make(d->r_map.seg, d->r_map.stride, d->r_map.off, d->r_map.inner);
+    // 256 x 256 tiles: the persistent kernel - one workgroup per CU walks its tiles; a launch with fewer tiles than CUs simply
+    // leaves workgroups with one tile or none.  It addresses its operands as a tile base + 32-bit per-lane offsets: K >= 128,
+    // a tile's 256 rows of A (through a_map: monotone maps only) and of W within 2 GiB of the tile's first row; the
+    // LayerNorm-fold instance only carries the LDS-staged epilogues.  Anything else runs on the 128 x 128 kernel (64-bit pointers).
     if (!force128 && use_256(a.M, a.N, a.K)) {
-        a.tiles_m = (a.M + 255) / 256;
-        a.tiles_n = (a.N + 255) / 256;
-        // group height of the tile order (choose_group_m above): fewest operand panels per window of 32 concurrent tiles.
-        // The order never changes a result.  (Diagnostics builds: TDC_GEMM_GROUP_M overrides.)
-        a.group_m = choose_group_m(a.tiles_m, a.tiles_n);
-#ifdef TDC_GEMM_DIAG
-        { const char* e = getenv("TDC_GEMM_GROUP_M"); if (e && atoi(e) > 0) a.group_m = atoi(e); }
-#endif
-        // hipFuncSetAttribute is per device: one flag per device and instantiation
-        const int dev = current_device();
-        static bool attr256_dev[kMaxDev];
-        bool& attr256 = attr256_dev[dev];
-        if (!attr256) {
-            HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm256_kernel<T, FP8>,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS));
-            attr256 = true;
-        }
-        // persistent form: more tiles than CUs, identity a_map, K >= 128, in-tile byte offsets fit 32 bits
-        // (the LayerNorm-fold instance only carries the LDS-staged epilogues)
         const int G = persistent_grid();
         const bool fold_ok = !d->ln_stats || d->out_fp8 || (d->out_f32 && d->res && d->res_f32 && d->act == TDC_ACT_NONE) ||
                              (!d->out_f32 && !(d->ldc & 7) && !((uintptr_t)d->C & 15) &&
                               d->N % (d->act == TDC_ACT_SWIGLU ? 16 : 8) == 0);
-        if (G > 0 && a.tiles_m * a.tiles_n > G && d->a_map.seg == 0 && a.K >= 128 && fold_ok &&
-            256ll * a.lda * 2 < (1ll << 31) && 256ll * a.ldw * 2 < (1ll << 31)) {
+        // rows of A a tile can span: identity 256; mapped m -> (m / seg) * stride + off + (m % seg) * inner, monotone when
+        // inner >= 1 and stride >= (seg - 1) * inner + 1: at most 256 / seg + 2 segments are touched
+        long long a_span = 256;
+        bool a_ok = true;
+        if (d->a_map.seg > 0) {
+            const long long seg = d->a_map.seg, stride = d->a_map.stride, inner = d->a_map.inner;
+            a_ok = inner >= 1 && stride >= (seg - 1) * inner + 1 && d->a_map.off >= 0;
+            a_span = (256 / seg + 2) * stride + seg * inner;
+        }
+        if (G > 0 && a_ok && a.K >= 128 && fold_ok && a_span * a.lda * 2 < (1ll << 31) && 256ll * a.ldw * 2 < (1ll << 31)) {
+            a.tiles_m = (a.M + 255) / 256;
+            a.tiles_n = (a.N + 255) / 256;
+            // group height of the tile order (choose_group_m above): fewest operand panels per window of 32 concurrent tiles.
+            // The order never changes a result.  (Diagnostics builds: TDC_GEMM_GROUP_M overrides.)
+            a.group_m = choose_group_m(a.tiles_m, a.tiles_n);
+#ifdef TDC_GEMM_DIAG
+            { const char* e = getenv("TDC_GEMM_GROUP_M"); if (e && atoi(e) > 0) a.group_m = atoi(e); }
+#endif
+            // hipFuncSetAttribute is per device: one flag per device and instantiation
             static bool attr256p_dev[kMaxDev];
-            bool& attr256p = attr256p_dev[dev];
+            bool& attr256p = attr256p_dev[current_device()];
             if (!attr256p) {
                 HIP_CHECK_RET(hipFuncSetAttribute((const void*)gemm256p_kernel<T, false, FP8>,
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, T2P_LDS));
@@ -1808,9 +1667,8 @@ int launch(const tdc_gemm_desc* d, hipStream_t st, bool force128 = false) {
             else hipLaunchKernelGGL((gemm256p_kernel<T, false, FP8>), dim3(G), dim3(512), T2P_LDS, st, a);
             return (int)hipGetLastError();
         }
-        hipLaunchKernelGGL((gemm256_kernel<T, FP8>), dim3(a.tiles_m * a.tiles_n), dim3(512), T2_LDS, st, a);
-        return (int)hipGetLastError();
     }
+    a.group_m = GROUP_M_DEFAULT;
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
     static bool attr_set_dev[kMaxDev];

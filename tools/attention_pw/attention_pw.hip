@@ -12,7 +12,7 @@
 // (tools/debug_attn_pw.py checks it against the library's kernel and fp32 SDPA) and SLOWER than attention32.hip on the tower shape
 // (B = 512, 24 heads, S = 730: 3.0-3.4 ms against 2.45-2.6 ms; S = 4096: 1.14-1.30 ms against 1.05-1.10 ms).  Built by
 // tools/attention_pw/build.sh into its own libtdc_attn_pw.so (entry: tdc_attn_pw_run, below), with tools/audit_asm_reads.py
-// run on the generated code as part of that build.  What was measured on the way (NOTES.md, round 4):
+// run on the generated code as part of that build.  What was measured on the way (profiles/archive/NOTES_rounds1-4.md 9.3):
 //  * MFMA stream + softmax alone - K / V fragments and tiles frozen - runs at 1 600 TFLOP/s equivalent: the exponentials DO hide
 //    under the wave's own MFMAs; MFMA stream + LDS-DMA + fragment reads without the softmax at ~1 300; all three together at
 //    600-720: with one wave per SIMD every LDS-DMA issue (50-250 cycles each, four per tile), every barrier skew and the whole
