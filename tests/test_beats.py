@@ -1,6 +1,7 @@
 """BEATs audio encoder.  CPU part: the oracle restatement against the fixture generated from the
 imported reference (tests/golden/make_golden_beats.py) and the known-answer anchors of the kaldi fbank restatement
-(torchaudio is absent: that stage is "parity unpinned").  GPU part: tests/test_hip_beats.py."""
+(torchaudio is absent: that stage is "parity unpinned" by the reference - and cross-checked against the kaldi-compatible
+implementation of transformers.audio_utils, an independent third party).  GPU part: tests/test_hip_beats.py."""
 import math
 import os
 import sys
@@ -88,3 +89,33 @@ def test_fbank_known_answers():
     assert torch.allclose((b - a)[live], torch.full_like(a[live], math.log(16.0)), atol=1e-2)   # power scale law
     c = BO.kaldi_fbank(x + 500.0)                                                  # DC removal
     assert float((a - c).abs().max()) < 0.1
+
+
+def test_kaldi_fbank_restatement_vs_transformers_kaldi_compat():
+    """The kaldi fbank front end (tdc/audio_models/beats/BEATs.py:116-129 calls torchaudio.compliance.kaldi.fbank; torchaudio
+    is absent from this image and the reference holds no vectors, so this stage cannot be pinned by the reference's own
+    dependency) cross-checked against an INDEPENDENT third-party implementation that is installed: the kaldi-compatible path of
+    `transformers.audio_utils` (povey window, pre-emphasis 0.97, DC removal, kaldi mel scale triangularised in mel space, log with
+    the float32-epsilon floor) - the code HF's SeamlessM4T / AST feature extractors run in place of torchaudio's kaldi.fbank.
+    It computes in float64; the restatement in float32 like torchaudio: agreement 2e-3 max / 1e-5 mean on log-mel values in
+    [-16, 28] (measured 1.7e-3 / 8e-6), the same frame count, and the same mel filter bank."""
+    au = pytest.importorskip("transformers.audio_utils")
+    import warnings
+    window = au.window_function(400, "povey", periodic=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")          # "at least one mel filter has all zero values": true of kaldi's 128 bins at 512 points too
+        mel = au.mel_filter_bank(num_frequency_bins=257, num_mel_filters=128, min_frequency=20, max_frequency=8000,
+                                 sampling_rate=16000, norm=None, mel_scale="kaldi", triangularize_in_mel_space=True)
+    assert float(np.abs(mel.T[:, :256] - BO.mel_banks().numpy()[:, :256]).max()) < 5e-5     # fp32 (kaldi) vs float64 weights: 1.4e-5
+    g = torch.Generator().manual_seed(1)
+    for n, kind in [(16000 * 3 + 123, "chirp"), (16000 * 2, "noise"), (400, "one frame"), (16000 * 10, "noise")]:
+        t = torch.arange(n) / 16000.0
+        wav = (0.3 * torch.sin(2 * math.pi * (200 + 500 * t) * t) + 0.02 * torch.randn(n, generator=g)) if kind == "chirp" \
+            else 0.1 * torch.randn(n, generator=g)
+        mine = BO.kaldi_fbank(wav * 2 ** 15).numpy()
+        ref = au.spectrogram(wav.numpy().astype(np.float64) * 2 ** 15, window, frame_length=400, hop_length=160, fft_length=512,
+                             power=2.0, center=False, preemphasis=0.97, mel_filters=mel, log_mel="log",
+                             mel_floor=1.192092955078125e-07, remove_dc_offset=True).T
+        assert mine.shape == ref.shape == (1 + (n - 400) // 160, 128)
+        d = np.abs(mine - ref)
+        assert float(d.max()) < 5e-3 and float(d.mean()) < 2e-5, (kind, n, float(d.max()), float(d.mean()))
