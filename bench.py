@@ -27,7 +27,7 @@ MFMA_PEAK_TFLOPS = 2500.0   # dense bf16/fp16 MFMA peak, /opt/skills/guides/MI35
 # what back-to-back bf16 16x16x32 MFMAs on dense random REGISTER operands sustain at the chip's power limit (no memory traffic;
 # all-zero operands: 2448): tools/mfma_power.cpp, profiles/r02_mfma_power.log.  Reported beside `frac`, never instead of it.
 MFMA_DENSE_SUSTAINED_TFLOPS = 1899.0
-PMC_SUMMARY = "r04_gemm_pmc_summary.json"   # profiles/: counters of the current code (tools/run_gemm_pmc.sh), see `traffic_source`
+PMC_SUMMARY = "r05_gemm_pmc_summary.json"   # profiles/: counters of the current code (tools/run_gemm_pmc.sh), see `traffic_source`
 
 
 def model_cfg(H, K, T):

@@ -180,12 +180,14 @@ class VideoEncoder:
         return out
 
     def _tower_batch(self, t, px, out_grid):
+        """One tower batch.  Default: the C++ composite (tdc_vit_fwd).  With `native_towers = False`: the SAME launches issued one
+        by one from Python - the form the tests compare the composite with, bit for bit - over either residual stream
+        (`tower_res_dtype`: None = fp32, read-modify-written as 8 B per element; a 16-bit type = tdc_vit_model.res_dtype_p1)."""
         if getattr(self, "native_towers", True) and len(t.layers) > 0:
             return self._tower_batch_native(t, px, out_grid)
         dt, dev = self.tower_dtype, self.dev
         rd = getattr(self, "tower_res_dtype", None)
-        if rd is not None:
-            return self._tower_batch_res16(t, px, out_grid, rd)
+        s32 = rd is None                         # fp32 residual stream
         B = px.shape[0]
         D, Dp = t.dim, pad64(t.dim)
         patches, gh, gw = ops.im2col(px, t.patch, dt)
@@ -193,11 +195,17 @@ class VideoEncoder:
         P = gh * gw
         S = P + t.has_cls
         pos, cls_row = Wt.tower_pos(t, gh, gw, dev)
-        x32 = torch.empty(B * S, Dp, device=dev, dtype=torch.float32)
-        ops.gemm(patches, t.patch_lin.w, t.patch_lin.b, res=pos, r_map=(P, 0, t.has_cls, 1), out=x32, out_f32=True,
+        x = torch.empty(B * S, Dp, device=dev, dtype=torch.float32 if s32 else rd)        # the residual stream
+        ops.gemm(patches, t.patch_lin.w, t.patch_lin.b, res=pos, r_map=(P, 0, t.has_cls, 1), out=x, out_f32=s32,
                  c_map=(P, S, t.has_cls, 1))
         if t.has_cls:
-            ops.set_rows(x32, B, S, 0, cls_row)
+            (ops.set_rows if s32 else ops.set_rows16)(x, B, S, 0, cls_row)
+
+        def ln(g, b, **kw):                      # LayerNorm of the stream -> 16-bit operand rows (or e4m3 rows + scales)
+            return ops.layernorm(x, g, b, t.eps, D, dt, x16_kernel=not s32, **kw)
+
+        def update(a, lin, **kw):                # x <- x + a lin^T + b, in place (fp32: 8 B per element; 16-bit: one rounding)
+            return ops.gemm(a, lin.w, lin.b, res=x, out=x, out_f32=s32, **kw)
         h16 = torch.empty(B * S, Dp, device=dev, dtype=dt)
         qkv = torch.empty(B * S, t.layers[0].qkv.w.shape[0], device=dev, dtype=dt) if t.layers else None
         attn = torch.zeros(B * S, Dp, device=dev, dtype=dt)
@@ -208,11 +216,12 @@ class VideoEncoder:
         # t.fused: the block's LayerNorms are folded into the GEMMs around them - the residual-stream GEMM emits the
         # 16-bit row copy (into h16) and per-slot statistics, the next GEMM folds (mean, rstd) into its epilogue
         fused = bool(t.fused)
+        fp8 = int(t.get("fp8") or 0)
+        assert s32 or not (fused or fp8), "the LayerNorm fold and the fp8 towers keep the fp32 residual stream"
         slots = D // 64
         part = torch.empty(slots, B * S, 2, device=dev, dtype=torch.float32) if fused else None
         stats = torch.empty(B * S, 2, device=dev, dtype=torch.float32) if fused else None
         emit = dict(x16=h16, ln_part=part) if fused else {}
-        fp8 = int(t.get("fp8") or 0)
         if fp8:     # e4m3 LayerNorm rows (per-row scales in `stats`) for the fp8-operand qkv / fc1 GEMMs
             h8 = torch.empty(B * S, t.layers[0].qkv.w.shape[1], device=dev, dtype=torch.uint8)
             stats = torch.empty(B * S, 2, device=dev, dtype=torch.float32)
@@ -226,10 +235,10 @@ class VideoEncoder:
             stats2 = torch.empty(B * S, 2, device=dev, dtype=torch.float32)
         for li, Lr in enumerate(t.layers):
             if fp8:
-                ops.layernorm(x32, Lr.ln1_g, Lr.ln1_b, t.eps, D, dt, y8=h8, y8_stats=stats, y8_wscale=Lr.qkv.wscale)
+                ln(Lr.ln1_g, Lr.ln1_b, y8=h8, y8_stats=stats, y8_wscale=Lr.qkv.wscale)
                 ops.gemm(h8, Lr.qkv.w, Lr.qkv.b, out=qkv, ln_stats=stats, ln_c1=Lr.qkv.zeros, out_dtype=dt)
             elif Lr.qkv_c1 is None:
-                ops.layernorm(x32, Lr.ln1_g, Lr.ln1_b, t.eps, D, dt, y16=h16)
+                ln(Lr.ln1_g, Lr.ln1_b, y16=h16)
                 ops.gemm(h16, Lr.qkv.w, Lr.qkv.b, out=qkv)
             else:
                 ops.gemm(h16, Lr.qkv.w, Lr.qkv.b, out=qkv, ln_stats=stats, ln_c1=Lr.qkv_c1)
@@ -238,75 +247,35 @@ class VideoEncoder:
                           S * ld, S * ld, S * ld, S * attn.stride(0))
             if fp8 >= 2:
                 ops.quantize_rows_fp8(attn, Dp, Lr.out.wscale, y8=a8, stats=stats)
-                ops.gemm(a8, Lr.out.w, Lr.out.b, res=x32, out=x32, out_f32=True, ln_stats=stats, ln_c1=Lr.out.zeros,
-                         out_dtype=dt)
+                update(a8, Lr.out, ln_stats=stats, ln_c1=Lr.out.zeros, out_dtype=dt)
             else:
-                ops.gemm(attn, Lr.out.w, Lr.out.b, res=x32, out=x32, out_f32=True, **emit)
+                update(attn, Lr.out, **emit)
             if fused:
                 ops.ln_finalize(part, slots, B * S, t.eps, stats)
                 ops.gemm(h16, Lr.fc1.w, Lr.fc1.b, act=act, out=mlp, ln_stats=stats, ln_c1=Lr.fc1_c1)
             elif fp8:
-                ops.layernorm(x32, Lr.ln2_g, Lr.ln2_b, t.eps, D, dt, y8=h8, y8_stats=stats, y8_wscale=Lr.fc1.wscale)
+                ln(Lr.ln2_g, Lr.ln2_b, y8=h8, y8_stats=stats, y8_wscale=Lr.fc1.wscale)
                 if fp8 >= 3:
                     ops.gemm(h8, Lr.fc1.w, Lr.fc1.b, act=act, out=m8, ln_stats=stats, ln_c1=Lr.fc1.zeros, out_dtype=dt,
                              out_stats=stats2, out_w2max=Lr.fc1.w2max, out_bmax=Lr.fc1.bmax, out_wscale=Lr.fc2.wscale)
                 else:
                     ops.gemm(h8, Lr.fc1.w, Lr.fc1.b, act=act, out=mlp, ln_stats=stats, ln_c1=Lr.fc1.zeros, out_dtype=dt)
             else:
-                ops.layernorm(x32, Lr.ln2_g, Lr.ln2_b, t.eps, D, dt, y16=h16)
+                ln(Lr.ln2_g, Lr.ln2_b, y16=h16)
                 ops.gemm(h16, Lr.fc1.w, Lr.fc1.b, act=act, out=mlp)
             if fp8 >= 3:
-                ops.gemm(m8, Lr.fc2.w, Lr.fc2.b, res=x32, out=x32, out_f32=True, ln_stats=stats2, ln_c1=Lr.fc2.zeros,
-                         out_dtype=dt)
+                update(m8, Lr.fc2, ln_stats=stats2, ln_c1=Lr.fc2.zeros, out_dtype=dt)
             elif fp8 == 2:
                 ops.quantize_rows_fp8(mlp, mlp_n, Lr.fc2.wscale, y8=m8, stats=stats)
-                ops.gemm(m8, Lr.fc2.w, Lr.fc2.b, res=x32, out=x32, out_f32=True, ln_stats=stats, ln_c1=Lr.fc2.zeros,
-                         out_dtype=dt)
+                update(m8, Lr.fc2, ln_stats=stats, ln_c1=Lr.fc2.zeros, out_dtype=dt)
             elif fused and li + 1 < len(t.layers):
-                ops.gemm(mlp, Lr.fc2.w, Lr.fc2.b, res=x32, out=x32, out_f32=True, **emit)
+                update(mlp, Lr.fc2, **emit)
                 ops.ln_finalize(part, slots, B * S, t.eps, stats)
             else:
-                ops.gemm(mlp, Lr.fc2.w, Lr.fc2.b, res=x32, out=x32, out_f32=True)
-        src = x32
+                update(mlp, Lr.fc2)
+        src, sdt = x, (dt if s32 else rd)
         if t.get("final_ln"):
-            ops.layernorm(x32, t.final_ln[0], t.final_ln[1], t.eps, D, dt, y16=h16)
-            src = h16
-        return ops.resample_tokens(src, B, t.has_cls, gh, out_grid, D, dt, self._bil(gh, out_grid), out_dtype=self.dtype)
-
-    def _tower_batch_res16(self, t, px, out_grid, rd):
-        """per-kernel sequence of a tower batch over a 16-bit residual stream of type `rd` (== tdc_vit_fwd with res_dtype_p1)"""
-        dt, dev = self.tower_dtype, self.dev
-        B = px.shape[0]
-        D, Dp = t.dim, pad64(t.dim)
-        patches, gh, gw = ops.im2col(px, t.patch, dt)
-        assert gh == gw, "square inputs only (reference pads to square, mm_datautils.py:286-314)"
-        P = gh * gw
-        S = P + t.has_cls
-        pos, cls_row = Wt.tower_pos(t, gh, gw, dev)
-        x16 = torch.empty(B * S, Dp, device=dev, dtype=rd)
-        ops.gemm(patches, t.patch_lin.w, t.patch_lin.b, res=pos, r_map=(P, 0, t.has_cls, 1), out=x16,
-                 c_map=(P, S, t.has_cls, 1))
-        if t.has_cls:
-            ops.set_rows16(x16, B, S, 0, cls_row)
-        h16 = torch.empty(B * S, Dp, device=dev, dtype=dt)
-        qkv = torch.empty(B * S, t.layers[0].qkv.w.shape[0], device=dev, dtype=dt)
-        attn = torch.zeros(B * S, Dp, device=dev, dtype=dt)
-        act = {"gelu_tanh": L.ACT_GELU_TANH, "gelu_erf": L.ACT_GELU_ERF, "swiglu": L.ACT_SWIGLU}[t.act]
-        mlp = torch.empty(B * S, t.layers[0].fc2.w.shape[1], device=dev, dtype=dt)
-        scale = t.head_dim ** -0.5
-        for Lr in t.layers:
-            ops.layernorm(x16, Lr.ln1_g, Lr.ln1_b, t.eps, D, dt, y16=h16, x16_kernel=True)
-            ops.gemm(h16, Lr.qkv.w, Lr.qkv.b, out=qkv)
-            ld = qkv.stride(0)
-            ops.attention(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], attn, B, t.heads, t.head_dim, S, S, scale,
-                          S * ld, S * ld, S * ld, S * attn.stride(0))
-            ops.gemm(attn, Lr.out.w, Lr.out.b, res=x16, out=x16)
-            ops.layernorm(x16, Lr.ln2_g, Lr.ln2_b, t.eps, D, dt, y16=h16, x16_kernel=True)
-            ops.gemm(h16, Lr.fc1.w, Lr.fc1.b, act=act, out=mlp)
-            ops.gemm(mlp, Lr.fc2.w, Lr.fc2.b, res=x16, out=x16)
-        src, sdt = x16, rd
-        if t.get("final_ln"):
-            ops.layernorm(x16, t.final_ln[0], t.final_ln[1], t.eps, D, dt, y16=h16, x16_kernel=True)
+            ln(t.final_ln[0], t.final_ln[1], y16=h16)
             src, sdt = h16, dt
         return ops.resample_tokens(src, B, t.has_cls, gh, out_grid, D, sdt, self._bil(gh, out_grid), out_dtype=self.dtype)
 

@@ -82,7 +82,7 @@ def check(S):
     print("S=%d ok (max error against fp32 SDPA %.2e)" % (S, worst), flush=True)
 
 
-for S in (730, 729, 256, 192, 193, 320, 1501):
+for S in (730, 729, 256, 320, 1501):          # (the form needs >= 256 query rows and >= 192 keys)
     check(S)
 
 g = torch.Generator(device="cuda").manual_seed(0)
