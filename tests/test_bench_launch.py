@@ -81,3 +81,23 @@ def test_rank_guard_ends_a_stuck_rank_with_124():
     code = ("import sys, time; sys.path.insert(0, %r); import bench; bench.rank_guard(1.0); time.sleep(60)" % ROOT)
     r = subprocess.run([sys.executable, "-c", code], env=_env(), capture_output=True, text=True, timeout=120)
     assert r.returncode == 124 and "rank-timeout" in r.stderr
+
+
+@pytest.mark.gpu
+def test_torchrun_form_of_the_drivers_scaling_run_on_one_gpu():
+    """The driver's N > 1 command line - python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ... - with both ranks on cuda:0 over gloo (the bench's test hooks): bench.py must run as a
+    rank (not launch ranks of its own), print ONE JSON line on rank 0 and leave the process group cleanly."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "64",
+                        "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                       env=_env(TDC_BENCH_ONE_GPU="1", TDC_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["ranks_seen"] == [0, 1] and res["value"] > 0 and res["scaling"] == "strong"
