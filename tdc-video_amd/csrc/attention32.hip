@@ -192,6 +192,9 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(AttnArgs p) {
 
         // ---- S^T = K Q^T: s[qb][kb] holds, for query r, keys kv0 + 32 kb + (e & 3) + 8 (e >> 2) + 4 hh
         f32x16 s[QB][2];
+#ifdef ATTN32_MFMA_PRIO
+        __builtin_amdgcn_s_setprio(ATTN32_MFMA_PRIO);
+#endif
 #pragma unroll
         for (int qb = 0; qb < NQ; ++qb)
 #pragma unroll
@@ -208,8 +211,14 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(AttnArgs p) {
                 for (int qb = 0; qb < NQ; ++qb) s[qb][kb] = mfma32(kf, qf[qb][ks], s[qb][kb]);
             }
         }
+#ifdef ATTN32_MFMA_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         // ---- online softmax in base 2 on the raw scores; P^T fragments in place
         v8 pf[QB][2][2];
+#ifdef ATTN32_PRIO        // experiment: the softmax section at a raised wave priority (it is the partner wave's MFMAs it should run beside)
+        __builtin_amdgcn_s_setprio(ATTN32_PRIO);
+#endif
 #pragma unroll
         for (int qb = 0; qb < NQ; ++qb) {
             if (PARTIAL) {
@@ -233,6 +242,30 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(AttnArgs p) {
             const float m_new = (m_cand > m_run[qb] + ATTN32_THR) ? m_cand : m_run[qb];
             const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
             m_run[qb] = m_new;
+#ifndef ATTN32_PACKED
+            // exponent arguments and row sums as SINGLE-value fma / add (two accumulators): packed fp32 arithmetic (v_pk_fma_f32 /
+            // v_pk_add_f32) halves the instruction count but never runs beside the partner wave's MFMAs (tools/mfma_valu_overlap.cpp,
+            // MI355X_MICROARCH.md "packed f32 VALU ... an anti-lever beside MFMAs"); round 5, same box, three runs each
+            // (profiles/r05_attention32_scalar_ab.log): d = 64 716-733 -> 744-756 TFLOP/s, d = 72 512-518 -> 512-522.  The empty
+            // asm keeps the SLP vectoriser from re-packing the pairs.  (-DATTN32_PACKED: the packed form of rounds 2-4.)
+            float rs0 = 0.f, rs1 = 0.f;
+            const float nm = -m_new;
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        float z0 = __builtin_fmaf(s[qb][kb][st * 8 + j], c, nm), z1 = __builtin_fmaf(s[qb][kb][st * 8 + j + 1], c, nm);
+                        asm volatile("" : "+v"(z0), "+v"(z1));
+                        const float e0 = __builtin_amdgcn_exp2f(z0), e1 = __builtin_amdgcn_exp2f(z1);
+                        rs0 += e0; rs1 += e1;
+                        const typename VecOf<T>::v2 e16 = cvt2<T>(e0, e1);
+                        pf[qb][kb][st][j] = e16[0];
+                        pf[qb][kb][st][j + 1] = e16[1];
+                    }
+            l_run[qb] = l_run[qb] * alpha + (rs0 + rs1);
+#else
             // exponent arguments and row sums on register pairs (v_pk_fma_f32 / v_pk_add_f32: one issue slot per two values)
             const f32x2_t c2 = {c, c}, nm2 = {-m_new, -m_new};
             f32x2_t rs2 = {0.f, 0.f};
@@ -250,6 +283,7 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(AttnArgs p) {
                         pf[qb][kb][st][j + 1] = e16[1];
                     }
             l_run[qb] = l_run[qb] * alpha + (rs2[0] + rs2[1]);
+#endif
             // the running max only moves in the first few tiles: skip the O rescale when no lane's max changed
             if (!__all(alpha == 1.0f)) {
 #pragma unroll
@@ -258,6 +292,12 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(AttnArgs p) {
                     for (int e = 0; e < 16; ++e) o_acc[qb][db][e] *= alpha;
             }
         }
+#ifdef ATTN32_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef ATTN32_MFMA_PRIO
+        __builtin_amdgcn_s_setprio(ATTN32_MFMA_PRIO);
+#endif
         // ---- O^T += V^T P^T.  16-lane group G of the wave (r >> 4 within each half) reads the 4-key x 16-column block at keys
         //      32 kb + 16 st + 4 hh (+ 8), columns 32 db + 16 (r >> 4): lane 4 q + pp supplies row q, columns 4 pp ..
 #pragma unroll
@@ -281,6 +321,9 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(AttnArgs p) {
                     for (int qb = 0; qb < NQ; ++qb) o_acc[qb][db] = mfma32(vf, pf[qb][kb][st], o_acc[qb][db]);
                 }
         }
+#ifdef ATTN32_MFMA_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         __syncthreads();    // tile t+1 is visible; everyone is done reading tile t
     };
 

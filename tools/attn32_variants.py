@@ -25,9 +25,11 @@ ref = os.path.join(ROOT, "tools", "attention32_head.txt")      # committed sourc
 if os.path.exists(ref):
     open(base_src, "w").write(open(ref).read())
 # (name, source, extra hipcc arguments): edit to the experiment at hand
+tree = os.path.join(csrc, "attention32.hip")
 variants = [("committed source", base_src, []),
-            ("working tree", os.path.join(csrc, "attention32.hip"), []),
-            ("working tree, -fno-slp-vectorize", os.path.join(csrc, "attention32.hip"), ["-fno-slp-vectorize"])]
+            ("working tree", tree, []),
+            ("working tree, packed softmax arithmetic (rounds 2-4)", tree, ["-DATTN32_PACKED"]),
+            ("working tree (again)", tree, [])]
 g = torch.Generator(device="cuda").manual_seed(0)
 shapes = [(16, 72, 729), (24, 64, 730)]
 data = {}
@@ -41,7 +43,8 @@ for vi, (name, src, extra) in enumerate(variants):
         continue
     so = os.path.join(scratch, "attn32_variant_%d.so" % vi)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-w",
-                           "-mllvm", "--amdgpu-mfma-vgpr-form", "-fno-honor-nans", *extra, src, os.path.join(csrc, "attention.hip"), "-o", so])
+                           "-mllvm", "--amdgpu-mfma-vgpr-form", "-fno-honor-nans", *extra, src, os.path.join(csrc, "attention.hip"), "-x", "hip", os.path.join(csrc, "profile.cpp"),
+                           "-o", so])
     lib = C.CDLL(so)
     lib.tdc_attention.restype = C.c_int
     lib.tdc_attention.argtypes = [C.POINTER(L.AttnDesc), C.c_void_p]
