@@ -268,6 +268,82 @@ __global__ __launch_bounds__(256) void sva_kernel(SvaArgs p) {
     }
 }
 
+// The same attention for the shapes the path runs it on (C = 1024, 16 heads of 64: head dim % 8 == 0, dim / 8 threads per query
+// dividing 256, 16-byte aligned rows): HBM-bound byte work - per query 2 KB of q, 8 keys x (2 KB K + 2 KB V), 2 KB out - done
+// with 16-byte accesses and every load of a lane in flight at once.  A thread owns 8 consecutive channels of one query; the
+// hd / 8 lanes of a head combine their partial dot products with xor-shuffles (a fixed tree: deterministic), every lane of the
+// head then holds the head's <= 8 scores and runs the masked softmax redundantly, and the weighted V rows leave as one 16-byte
+// store per lane.  No LDS, no atomics, no barrier.  (The kernel above - 2-byte loads, 32 wave reductions and LDS atomics per
+// thread - moved 2.5 GB per launch in 1.86 ms at the bench's size: 1.3 TB/s; it stays for the odd shapes of the small fixtures.)
+// NT towers x R x R keys are compile-time: the per-key registers below must be indexed by constants (a register array indexed
+// by a run-time loop variable lives in scratch: the first version of this kernel ran at 0.4 TB/s)
+template <class T, int NT, int R>
+__global__ __launch_bounds__(256) void sva8_kernel(SvaArgs p, long long nq_total) {
+    constexpr int NKV = NT * R * R;
+    typedef typename VecOf<T>::v8 v8;
+    const int tpq = p.dim >> 3;                              // threads per query
+    const int qpw = 256 / tpq;                               // queries per workgroup
+    const int ql = threadIdx.x / tpq, ct = threadIdx.x - ql * tpq;
+    long long qi = (long long)blockIdx.x * qpw + ql;
+    const bool valid = qi < nq_total;
+    if (!valid) qi = nq_total - 1;                           // whole heads (lane groups) are valid or not: no exit before the shuffles
+    const int nq = p.side * p.side;
+    const int t = (int)(qi / nq), w = (int)(qi - (long long)t * nq);
+    const int wi = w / p.side, wj = w - wi * p.side;
+    const int n = p.side * R;
+    const int hd = p.dim / p.heads, lph = hd >> 3;           // lanes per head: a power of two (host)
+    const int c = ct * 8;
+    const v8 q8 = *(const v8*)((const T*)p.q + qi * p.ldq + c);
+    v8 k8[NKV], v8r[NKV];
+    bool ok[NKV];
+#pragma unroll
+    for (int tw = 0; tw < NT; ++tw)
+#pragma unroll
+        for (int a = 0; a < R; ++a)
+#pragma unroll
+            for (int b = 0; b < R; ++b) {
+                const int key = (tw * R + a) * R + b;
+                const long long tok = (long long)t * n * n + (wi * R + a) * n + (wj * R + b);
+                const T* row = (const T*)p.kv[tw] + tok * p.ldkv + c;
+                k8[key] = *(const v8*)row;
+                v8r[key] = *(const v8*)(row + p.dim);
+                ok[key] = p.mask[qi * NKV + key] != 0;
+            }
+    float qf[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qf[e] = (float)q8[e];
+    const float scale = rsqrtf((float)hd);
+    float sc[NKV];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int key = 0; key < NKV; ++key) {
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d = __builtin_fmaf(qf[e], (float)k8[key][e], d);
+        for (int o = 1; o < lph; o <<= 1) d += __shfl_xor(d, o);
+        sc[key] = ok[key] ? d * scale : -INFINITY;
+        mx = fmaxf(mx, sc[key]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int key = 0; key < NKV; ++key) { sc[key] = __expf(sc[key] - mx); sum += sc[key]; }
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int key = 0; key < NKV; ++key) {
+        const float pr = sc[key] / sum;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += pr * (float)v8r[key][e];
+    }
+    if (valid) {
+        v8 o8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o8[e] = (T)acc[e];
+        *(v8*)((T*)p.out + qi * p.ldo + c) = o8;
+    }
+}
+
 }  // namespace
 
 #define DISPATCH(dtype, CALL)                       \
@@ -368,6 +444,20 @@ extern "C" int tdc_sva_attention(const tdc_sva_attn_desc* d, void* stream) {
     a.dim = d->dim; a.heads = d->heads;
     hipStream_t st = (hipStream_t)stream;
     const int nq = d->T * d->side * d->side;
+    // the 16-byte-access kernel where the shape allows it (the path's own: C = 1024, 16 heads): 8-channel threads must tile whole
+    // heads, a query's threads a workgroup, and every row start must be 16-byte aligned
+    const int hd = d->dim / d->heads, lph = hd >> 3, tpq = d->dim >> 3;
+    const bool fast = d->r == 2 && d->dim % 8 == 0 && hd % 8 == 0 && lph >= 1 && lph <= 64 && (lph & (lph - 1)) == 0 && tpq <= 256 &&
+                      256 % tpq == 0 && tpq % lph == 0 && !(d->ldq & 7) && !(d->ldkv & 7) && !(d->ldo & 7) &&
+                      !((uintptr_t)d->q & 15) && !((uintptr_t)d->kv[0] & 15) && !((uintptr_t)d->out & 15) &&
+                      (d->n_towers < 2 || !((uintptr_t)d->kv[1] & 15));
+    if (fast) {
+        const int qpw = 256 / tpq;
+        const dim3 grid((nq + qpw - 1) / qpw);
+        if (d->n_towers == 2) { DISPATCH(d->dtype, hipLaunchKernelGGL((sva8_kernel<TT, 2, 2>), grid, dim3(256), 0, st, a, (long long)nq)); }
+        else { DISPATCH(d->dtype, hipLaunchKernelGGL((sva8_kernel<TT, 1, 2>), grid, dim3(256), 0, st, a, (long long)nq)); }
+        return (int)hipGetLastError();
+    }
     DISPATCH(d->dtype, hipLaunchKernelGGL(sva_kernel<TT>, dim3(nq), dim3(256), 0, st, a));
     return (int)hipGetLastError();
 }

@@ -472,15 +472,20 @@ def test_small_kernels(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("dim,heads", [(64, 16), (1024, 16)])
-def test_sva_attention(ops, dtype, dim, heads):
+@pytest.mark.parametrize("dim,heads,towers", [(64, 16, 2), (1024, 16, 2), (512, 8, 2), (2048, 16, 2), (256, 16, 2), (1024, 16, 1),
+                                              (1032, 3, 2)])
+def test_sva_attention(ops, dtype, dim, heads, towers):
+    """(64, 16): head dim 4 - the element-wise kernel; the others (head dim % 8 == 0, dim / 8 threads per query dividing 256) the
+    16-byte-access kernel with 2 / 4 / 1 / 8 queries per workgroup (18 queries: a partly filled last workgroup), 8 / 16 / 2 lanes
+    per head, one tower (4 keys); (1032, 3): head dim 344 = 43 lanes per head - not a power of two, back to the element-wise kernel."""
     g = torch.Generator(device="cuda").manual_seed(6)
     T, side, r = 2, 3, 2
     n = side * r
     nq = T * side * side
+    nkv = towers * r * r
     q = torch.randn(nq, dim, device="cuda", generator=g).to(dtype)
-    kv = [torch.randn(T * n * n, 2 * dim, device="cuda", generator=g).to(dtype) for _ in range(2)]
-    mask = (torch.rand(nq, 8, device="cuda", generator=g) > 0.3)
+    kv = [torch.randn(T * n * n, 2 * dim, device="cuda", generator=g).to(dtype) for _ in range(towers)]
+    mask = (torch.rand(nq, nkv, device="cuda", generator=g) > 0.3)
     mask[:, 0] = True
     out = ops.sva_attention(q, kv, mask.to(torch.uint8).contiguous(), T, side, r, dim, heads)
     # reference: gather the 2x2 windows
@@ -490,12 +495,15 @@ def test_sva_attention(ops, dtype, dim, heads):
     V = torch.cat([win(t[:, dim:].float()) for t in kv], 1)
     hd = dim // heads
     qh = q.float().view(nq, heads, 1, hd)
-    kh = K.view(nq, 8, heads, hd).transpose(1, 2)
-    vh = V.view(nq, 8, heads, hd).transpose(1, 2)
+    kh = K.view(nq, nkv, heads, hd).transpose(1, 2)
+    vh = V.view(nq, nkv, heads, hd).transpose(1, 2)
     s = (qh @ kh.transpose(-1, -2)) / math.sqrt(hd)
     s = s.masked_fill(~mask[:, None, None, :], float("-inf"))
     ref = (torch.softmax(s, -1) @ vh).reshape(nq, dim)
     assert relerr(out[:, :dim], ref) < 2 * tol(dtype)
+    lph = hd // 8
+    if hd % 8 == 0 and lph & (lph - 1) == 0:      # the 16-byte-access kernel reduces in a fixed tree (the other one: LDS atomics)
+        assert torch.equal(out, ops.sva_attention(q, kv, mask.to(torch.uint8).contiguous(), T, side, r, dim, heads))
 
 
 @pytest.mark.parametrize("dtype", DT)
