@@ -71,6 +71,42 @@ __global__ __launch_bounds__(256) void resample_kernel(const void* x, int x_f32,
     }
 }
 
+// the same for 16-bit inputs with 16-byte aligned rows (every tower launch): a thread resamples 8 consecutive columns - four
+// 16-byte loads, one 16-byte store; two output tokens per 256-thread workgroup at the towers' widths (the element-wise kernel
+// above ran the 27 x 27 -> 24 x 24 resample of a 512-frame batch at 1.4 TB/s).  Same expression per element: same bits.
+template <class T, class TO>
+__global__ __launch_bounds__(256) void resample8_kernel(const T* x, int ldx, int tok_off, int n_in, TO* y, int ldy, int n_out,
+                                                        const int* i0, const int* i1, const float* fr, int cols, int tpt,
+                                                        long long n_tok) {
+    typedef typename VecOf<T>::v8 v8;
+    typedef typename VecOf<TO>::v8 v8o;
+    const int tl = threadIdx.x / tpt, ct = threadIdx.x - tl * tpt;          // token within the workgroup, 8-column chunk
+    const long long tk = (long long)blockIdx.x * (256 / tpt) + tl;            // flat output token (b, oy, ox)
+    const int c = ct * 8;
+    if (tk >= n_tok || c >= ldy) return;
+    const int per = n_out * n_out;
+    const int b = (int)(tk / per), o = (int)(tk - (long long)b * per);
+    const int oy = o / n_out, ox = o - oy * n_out;
+    const int y0 = i0[oy], y1 = i1[oy], x0 = i0[ox], x1 = i1[ox];
+    const float fy = fr[oy], fx = fr[ox];
+    const long long base = (long long)b * (tok_off + n_in * n_in) + tok_off;
+    v8o out8;
+    if (c < cols) {      // cols % 8 == 0 (host): a chunk is valid as a whole
+        const v8 a8 = *(const v8*)(x + (base + y0 * n_in + x0) * ldx + c), b8 = *(const v8*)(x + (base + y0 * n_in + x1) * ldx + c);
+        const v8 c8 = *(const v8*)(x + (base + y1 * n_in + x0) * ldx + c), d8 = *(const v8*)(x + (base + y1 * n_in + x1) * ldx + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float a = (float)a8[e], bb = (float)b8[e], cc = (float)c8[e], d = (float)d8[e];
+            const float v = (1.f - fy) * ((1.f - fx) * a + fx * bb) + fy * ((1.f - fx) * cc + fx * d);
+            out8[e] = (TO)v;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out8[e] = (TO)0.f;
+    }
+    *(v8o*)(y + tk * ldy + c) = out8;
+}
+
 // ------------------------------------------------------------------------------------------------ cos-sim
 // pass 1: partial sums of <f_t, f_t> and <f_t, f_{t+1}> (fp32, fixed reduction order => deterministic ranking);
 // grid (chunks, T).  pass 2: combine.
@@ -389,6 +425,20 @@ extern "C" int tdc_resample_tokens(const void* x, int x_f32, int ldx, int tok_of
     if (!x || !y || !idx0 || !idx1 || !frac || B <= 0) return TDC_E_BADARG;
     if ((dtype != TDC_F16 && dtype != TDC_BF16) || (out_dtype != TDC_F16 && out_dtype != TDC_BF16)) return TDC_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
+    if (!x_f32 && cols % 8 == 0 && !(ldx & 7) && !(ldy & 7) && !((uintptr_t)x & 15) && !((uintptr_t)y & 15) && ldy <= 2048) {
+        // threads per token: ldy / 8 rounded up to a power of two that divides 256
+        int tpt = 1;
+        while (tpt * 8 < ldy) tpt <<= 1;
+        const long long n_tok = (long long)B * n_out * n_out;
+        const int per_wg = 256 / tpt;
+        const dim3 grid8((unsigned)((n_tok + per_wg - 1) / per_wg));
+#define RESAMPLE8(TI, TO_) hipLaunchKernelGGL((resample8_kernel<TI, TO_>), grid8, dim3(256), 0, st, (const TI*)x, ldx, tok_off, \
+                                              n_in, (TO_*)y, ldy, n_out, idx0, idx1, frac, cols, tpt, n_tok)
+        if (dtype == TDC_F16) { if (out_dtype == TDC_F16) RESAMPLE8(f16, f16); else RESAMPLE8(f16, bf16); }
+        else { if (out_dtype == TDC_F16) RESAMPLE8(bf16, f16); else RESAMPLE8(bf16, bf16); }
+#undef RESAMPLE8
+        return (int)hipGetLastError();
+    }
     const dim3 grid(n_out * n_out, B);
 #define RESAMPLE(TI, TO_) hipLaunchKernelGGL((resample_kernel<TI, TO_>), grid, dim3(256), 0, st, x, x_f32, ldx, tok_off, \
                                              n_in, (TO_*)y, ldy, n_out, idx0, idx1, frac, cols)

@@ -444,6 +444,17 @@ def test_small_kernels(ops, dtype):
     grid = x.view(B, 1 + n_in * n_in, D)[:, 1:].reshape(B, n_in, n_in, D).permute(0, 3, 1, 2)
     refi = F.interpolate(grid, size=(n_out, n_out), mode="bilinear", align_corners=False)
     assert relerr(y[:, :D], refi.permute(0, 2, 3, 1).reshape(-1, D)) < tol(dtype)
+    # 16-bit inputs (the towers' own launches): the 16-byte-access kernel; widths with pad columns (72 of 128), the towers' own
+    # (1152: 144 of 256 threads busy), with and without a cls row, both output types; == the fp32-input (element-wise) kernel on
+    # the same values, bit for bit, and zero pad columns
+    for (Dw, off, n_i, n_o) in [(72, 0, 9, 8), (1152, 1, 5, 4), (64, 1, 27, 24)]:
+        x16 = torch.zeros(B * (off + n_i * n_i), ops.pad64(Dw), device="cuda", dtype=dtype)
+        x16[:, :Dw] = torch.randn(x16.shape[0], Dw, device="cuda", generator=g).to(dtype)
+        tabs = ops.bilinear_tables(n_i, n_o, "cuda")
+        for odt in DT:
+            a = ops.resample_tokens(x16, B, off, n_i, n_o, Dw, dtype, tabs, out_dtype=odt)
+            b = ops.resample_tokens(x16.float(), B, off, n_i, n_o, Dw, dtype, tabs, out_dtype=odt)
+            assert a.dtype == odt and torch.equal(a, b) and torch.count_nonzero(a[:, Dw:]) == 0
     # cosine similarity of adjacent frames
     T, n = 7, 64 * 40
     f = torch.randn(T, n, device="cuda", generator=g).to(dtype)
