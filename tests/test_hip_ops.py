@@ -437,6 +437,14 @@ def test_small_kernels(ops, dtype):
     pat, gh, gw = ops.im2col(px, 14, dtype)
     ref = F.unfold(px, 14, stride=14).transpose(1, 2).reshape(2 * gh * gw, -1)
     assert relerr(pat[:, :588], ref) < tol(dtype) and torch.count_nonzero(pat[:, 588:]) == 0
+    # 16-bit pixels go through the LDS-staged kernel (4-byte loads: widths that are even but not multiples of 8, trailing rows /
+    # columns dropped as by the "valid" patch conv; pixels of either 16-bit type): identical to the fp32-pixel (element-wise) kernel
+    for (Hh, Ww) in [(42, 56), (44, 54), (30, 378)]:
+        for pdt in DT:
+            p16 = torch.randn(2, 3, Hh, Ww, device="cuda", generator=g).to(pdt)
+            a, gh2, gw2 = ops.im2col(p16, 14, dtype)
+            b, _, _ = ops.im2col(p16.float(), 14, dtype)
+            assert (gh2, gw2) == (Hh // 14, Ww // 14) and torch.equal(a, b) and torch.count_nonzero(a[:, 588:]) == 0
     # resample == F.interpolate bilinear (with cls offset)
     B, n_in, n_out, D = 2, 9, 8, 64
     x = torch.randn(B * (1 + n_in * n_in), D, device="cuda", generator=g)
