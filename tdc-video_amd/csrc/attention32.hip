@@ -50,9 +50,8 @@ constexpr int KT32 = 64;   // keys per tile (2 key blocks of 32)
 #define ATTN32_THR 8.0f
 #endif
 
-// DK: QK^T contraction width (64 or 80), NDB: output blocks of 32 columns (2 or 3), QB: 32-row query blocks per wave, SEQ: a
-// tile's two 32-key blocks one after the other (do_tile)
-template <class T, int DK, int NDB, int QB, bool SEQ>
+// DK: QK^T contraction width (64 or 80), NDB: output blocks of 32 columns (2 or 3), QB: 32-row query blocks per wave
+template <class T, int DK, int NDB, int QB>
 __global__ __launch_bounds__(256, 2) void attn32_kernel(AttnArgs p) {
     typedef typename VecOf<T>::v8 v8;
     typedef typename VecOf<T>::v4 v4;
@@ -191,47 +190,41 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(AttnArgs p) {
             if (tile + 2 < ntiles) issue_loads((tile + 2) * KT32);
         }
 
-        // A tile's key blocks of 32 go through QK^T -> softmax -> PV together (SEQ = false: one online-softmax step per 64-key
-        // tile) or one after the other (SEQ = true: a step per 32 keys; S and P of one key block in registers at a time - 48
-        // registers less, which is what lets head dim 72 run two query blocks per wave).
-        constexpr int NB = SEQ ? NKB : 1, KPB = SEQ ? 1 : NKB;
-#pragma unroll
-        for (int blk = 0; blk < NB; ++blk) {
-        // ---- S^T = K Q^T: s[qb][kk] holds, for query r, keys kv0 + 32 kb + (e & 3) + 8 (e >> 2) + 4 hh  (kb = blk * KPB + kk)
-        f32x16 s[QB][KPB];
+        // ---- S^T = K Q^T: s[qb][kb] holds, for query r, keys kv0 + 32 kb + (e & 3) + 8 (e >> 2) + 4 hh
+        f32x16 s[QB][2];
 #pragma unroll
         for (int qb = 0; qb < NQ; ++qb)
 #pragma unroll
-            for (int kk = 0; kk < KPB; ++kk)
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) s[qb][kk][e] = 0.f;
+                for (int e = 0; e < 16; ++e) s[qb][kb][e] = 0.f;
 #pragma unroll
-        for (int kk = 0; kk < KPB; ++kk) {
-            const int key = (blk * KPB + kk) * 32 + r;
+        for (int kb = 0; kb < NKB; ++kb) {
+            const int key = kb * 32 + r;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const v8 kf = *(const v8*)(kt_ + key * KROW + (kswz(key, ks * 2 + hh) << 3));
 #pragma unroll
-                for (int qb = 0; qb < NQ; ++qb) s[qb][kk] = mfma32(kf, qf[qb][ks], s[qb][kk]);
+                for (int qb = 0; qb < NQ; ++qb) s[qb][kb] = mfma32(kf, qf[qb][ks], s[qb][kb]);
             }
         }
         // ---- online softmax in base 2 on the raw scores; P^T fragments in place
-        v8 pf[QB][KPB][2];
+        v8 pf[QB][2][2];
 #pragma unroll
         for (int qb = 0; qb < NQ; ++qb) {
             if (PARTIAL) {
 #pragma unroll
-                for (int kk = 0; kk < KPB; ++kk)
+                for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
-                        if (kv0 + (blk * KPB + kk) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh >= p.sk) s[qb][kk][e] = -INFINITY;
+                        if (kv0 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh >= p.sk) s[qb][kb][e] = -INFINITY;
             }
             float mx = fmaxf(s[qb][0][0], s[qb][0][1]);
 #pragma unroll
             for (int e = 2; e < 16; e += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[qb][0][e]), s[qb][0][e + 1]);
-            if (KPB == 2) {
+            if (NKB == 2) {
 #pragma unroll
-                for (int e = 0; e < 16; e += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[qb][KPB - 1][e]), s[qb][KPB - 1][e + 1]);
+                for (int e = 0; e < 16; e += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, s[qb][1][e]), s[qb][1][e + 1]);
             }
             mx = fmaxf(mx, other_half(mx));
             // deferred rescale (cdna_hip_programming.md T13): the running maximum only follows the tile's when that exceeds it by
@@ -240,29 +233,49 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(AttnArgs p) {
             const float m_new = (m_cand > m_run[qb] + ATTN32_THR) ? m_cand : m_run[qb];
             const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
             m_run[qb] = m_new;
+#ifndef ATTN32_PACKED
             // exponent arguments and row sums as SINGLE-value fma / add (two accumulators): packed fp32 arithmetic (v_pk_fma_f32 /
-            // v_pk_add_f32, rounds 2-4) halves the instruction count but never runs beside the partner wave's MFMAs
-            // (tools/mfma_valu_overlap.cpp, MI355X_MICROARCH.md "packed f32 VALU ... an anti-lever beside MFMAs"); round 5, two
-            // boxes (profiles/r05_attention32_scalar_ab.log): d = 64 716-733 -> 744-756 TFLOP/s, d = 72 512-518 -> 512-522;
-            // s_setprio around the softmax or around the MFMA sections: no gain.  The empty asm keeps the SLP vectoriser from
-            // re-packing the pairs.
+            // v_pk_add_f32) halves the instruction count but never runs beside the partner wave's MFMAs (tools/mfma_valu_overlap.cpp,
+            // MI355X_MICROARCH.md "packed f32 VALU ... an anti-lever beside MFMAs"); round 5, same box, three runs each
+            // (profiles/r05_attention32_scalar_ab.log): d = 64 716-733 -> 744-756 TFLOP/s, d = 72 512-518 -> 512-522; s_setprio around the
+            // softmax or around the MFMA sections: no gain.  The empty
+            // asm keeps the SLP vectoriser from re-packing the pairs.  (-DATTN32_PACKED: the packed form of rounds 2-4.)
             float rs0 = 0.f, rs1 = 0.f;
             const float nm = -m_new;
 #pragma unroll
-            for (int kk = 0; kk < KPB; ++kk)
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                 for (int st = 0; st < 2; ++st)
 #pragma unroll
                     for (int j = 0; j < 8; j += 2) {
-                        float z0 = __builtin_fmaf(s[qb][kk][st * 8 + j], c, nm), z1 = __builtin_fmaf(s[qb][kk][st * 8 + j + 1], c, nm);
+                        float z0 = __builtin_fmaf(s[qb][kb][st * 8 + j], c, nm), z1 = __builtin_fmaf(s[qb][kb][st * 8 + j + 1], c, nm);
                         asm volatile("" : "+v"(z0), "+v"(z1));
                         const float e0 = __builtin_amdgcn_exp2f(z0), e1 = __builtin_amdgcn_exp2f(z1);
                         rs0 += e0; rs1 += e1;
-                        const typename VecOf<T>::v2 e16 = cvt2<T>(e0, e1);     // one v_cvt_pk per pair, f16 too
-                        pf[qb][kk][st][j] = e16[0];
-                        pf[qb][kk][st][j + 1] = e16[1];
+                        const typename VecOf<T>::v2 e16 = cvt2<T>(e0, e1);
+                        pf[qb][kb][st][j] = e16[0];
+                        pf[qb][kb][st][j + 1] = e16[1];
                     }
             l_run[qb] = l_run[qb] * alpha + (rs0 + rs1);
+#else
+            // exponent arguments and row sums on register pairs (v_pk_fma_f32 / v_pk_add_f32: one issue slot per two values)
+            const f32x2_t c2 = {c, c}, nm2 = {-m_new, -m_new};
+            f32x2_t rs2 = {0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        const f32x2_t z = __builtin_elementwise_fma((f32x2_t){s[qb][kb][st * 8 + j], s[qb][kb][st * 8 + j + 1]}, c2, nm2);
+                        const f32x2_t e = {__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])};
+                        rs2 += e;
+                        const typename VecOf<T>::v2 e16 = cvt2<T>(e[0], e[1]);     // one v_cvt_pk per pair, f16 too
+                        pf[qb][kb][st][j] = e16[0];
+                        pf[qb][kb][st][j + 1] = e16[1];
+                    }
+            l_run[qb] = l_run[qb] * alpha + (rs2[0] + rs2[1]);
+#endif
             // the running max only moves in the first few tiles: skip the O rescale when no lane's max changed
             if (!__all(alpha == 1.0f)) {
 #pragma unroll
@@ -277,11 +290,11 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(AttnArgs p) {
         for (int db = 0; db < NDB; ++db) {
             if (NQ == 0) break;
 #pragma unroll
-            for (int kk = 0; kk < KPB; ++kk)
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                 for (int st = 0; st < 2; ++st) {
                     const int li = r & 15, qq = li >> 2, pp = li & 3;
-                    const int key = (blk * KPB + kk) * 32 + st * 16 + hh * 4 + qq;
+                    const int key = kb * 32 + st * 16 + hh * 4 + qq;
                     const int col = db * 32 + (r >> 4) * 16 + pp * 4;      // multiple of 4: chunk col >> 3, 8-byte half (col >> 2) & 1
                     const T* a0 = vt_ + key * VROW + (vswz(key, col >> 3) << 3) + (col & 4);
                     const T* a1 = vt_ + (key + 8) * VROW + (vswz(key + 8, col >> 3) << 3) + (col & 4);
@@ -291,10 +304,9 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(AttnArgs p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
 #pragma unroll
-                    for (int qb = 0; qb < NQ; ++qb) o_acc[qb][db] = mfma32(vf, pf[qb][kk][st], o_acc[qb][db]);
+                    for (int qb = 0; qb < NQ; ++qb) o_acc[qb][db] = mfma32(vf, pf[qb][kb][st], o_acc[qb][db]);
                 }
         }
-        }   // key-block group
         __syncthreads();    // tile t+1 is visible; everyone is done reading tile t
     };
 
@@ -341,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(AttnArgs p) {
     }
 }
 
-template <class T, int DK, int NDB, int QB, bool SEQ>
+template <class T, int DK, int NDB, int QB>
 int launch32(const AttnArgs& a, int batch, hipStream_t st) {
     constexpr int KCH = (DK / 8 <= 8) ? 8 : ((DK / 8) | 1);
     constexpr int lds = 2 * KT32 * (KCH * 8 + NDB * 32) * 2;
@@ -349,12 +361,12 @@ int launch32(const AttnArgs& a, int batch, hipStream_t st) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_dev[dev]) {
-        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn32_kernel<T, DK, NDB, QB, SEQ>,
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)attn32_kernel<T, DK, NDB, QB>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_dev[dev] = true;
     }
     dim3 grid(((a.sq + 128 * QB - 1) / (128 * QB)) * a.heads * batch);   // 1-D: the kernel maps ids to (batch, head, query block)
-    hipLaunchKernelGGL((attn32_kernel<T, DK, NDB, QB, SEQ>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((attn32_kernel<T, DK, NDB, QB>), grid, dim3(256), lds, st, a);
     return (int)hipGetLastError();
 }
 
@@ -363,13 +375,7 @@ int launch32(const AttnArgs& a, int batch, hipStream_t st) {
 // entry for attention.hip: returns -1 when this form does not apply (the caller falls through to the 16x16 kernels)
 int tdc_attention32(const AttnArgs& a, int batch, int dtype, hipStream_t st) {
     if (a.bias || !a.vec_ok || a.sq < 256 || a.sk < 64) return -1;
-#ifndef ATTN32_D72_QB
-#define ATTN32_D72_QB 1
-#define ATTN32_D72_SEQ false
-#endif
-    if (a.d == 64) return dtype == TDC_F16 ? launch32<f16, 64, 2, 2, false>(a, batch, st) : launch32<bf16, 64, 2, 2, false>(a, batch, st);
-    if (a.d > 64 && a.d <= 80)
-        return dtype == TDC_F16 ? launch32<f16, 80, 3, ATTN32_D72_QB, ATTN32_D72_SEQ>(a, batch, st)
-                                : launch32<bf16, 80, 3, ATTN32_D72_QB, ATTN32_D72_SEQ>(a, batch, st);
+    if (a.d == 64) return dtype == TDC_F16 ? launch32<f16, 64, 2, 2>(a, batch, st) : launch32<bf16, 64, 2, 2>(a, batch, st);
+    if (a.d > 64 && a.d <= 80) return dtype == TDC_F16 ? launch32<f16, 80, 3, 1>(a, batch, st) : launch32<bf16, 80, 3, 1>(a, batch, st);
     return -1;
 }

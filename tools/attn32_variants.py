@@ -28,9 +28,7 @@ if os.path.exists(ref):
 tree = os.path.join(csrc, "attention32.hip")
 variants = [("committed source", base_src, []),
             ("working tree", tree, []),
-            ("d = 72: two query blocks per wave, key blocks one after the other", tree, ["-DATTN32_D72_QB=2", "-DATTN32_D72_SEQ=true"]),
-            ("d = 72: one query block, key blocks one after the other", tree, ["-DATTN32_D72_QB=1", "-DATTN32_D72_SEQ=true"]),
-            ("committed source (again)", base_src, []),
+            ("working tree, packed softmax arithmetic (rounds 2-4)", tree, ["-DATTN32_PACKED"]),
             ("working tree (again)", tree, [])]
 g = torch.Generator(device="cuda").manual_seed(0)
 shapes = [(16, 72, 729), (24, 64, 730)]
