@@ -1174,9 +1174,18 @@ constexpr int T2_LDS = 2 * T2_BUF;            // 128 KiB
 #else
 #define TDC_DIAG_MMA_ON
 #endif
+// raised wave priority around the MFMA clusters: same-box A/B in round 5 (tools/lib_ab.sh on builds with -DTDC_GEMM_NOPRIO /
+// -DTDC_GEMM_PRIO_HI=3): without it the towers take 969 instead of 884 ms
+#if defined(TDC_GEMM_NOPRIO)
+#define TDC_SETPRIO(x)
+#elif defined(TDC_GEMM_PRIO_HI)
+#define TDC_SETPRIO(x) __builtin_amdgcn_s_setprio((x) ? TDC_GEMM_PRIO_HI : 0)
+#else
+#define TDC_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
+#endif
 #define T2_MMA(MI0, NJ0, fbx)                                                       \
     if (active TDC_DIAG_MMA_ON) {                                                   \
-        __builtin_amdgcn_s_setprio(1);                                              \
+        TDC_SETPRIO(1);                                                             \
         if constexpr (FP8) {                                                        \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                           \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                           \
@@ -1187,7 +1196,7 @@ constexpr int T2_LDS = 2 * T2_BUF;            // 128 KiB
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                           \
                 acc[(MI0) + i][(NJ0) + j] = mfma16(fbx[j][ks], fa[i][ks], acc[(MI0) + i][(NJ0) + j]); \
         }                                                                           \
-        __builtin_amdgcn_s_setprio(0);                                              \
+        TDC_SETPRIO(0);                                                             \
     }
 
 // ======================================================================================================================
