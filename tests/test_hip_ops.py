@@ -300,6 +300,59 @@ def test_gemm_row_maps(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("seg,stride,off", [(144, 156, 0), (12, 156, 144), (300, 301, 0), (7, 1000, 3), (64, 64, 0), (144, 100, 0)])
+def test_gemm_row_mapped_a_on_the_persistent_kernel(ops, dtype, seg, stride, off):
+    """Round 5: launches of 256 x 256 tiles with a row-mapped A (the Q-Former's query / text rows: (144, 156, 0), (12, 156, 144))
+    run on the persistent kernel, which stages a tile from its mapped first row + 32-bit per-lane offsets through the map.
+    Segments shorter and longer than a tile, a tile that spans 37 segments, a ragged last tile (M % 256 != 0), an offset, the
+    identity-like (64, 64, 0); (144, 100, 0) is NOT monotone (stride < seg): the launcher must send it to the 128 x 128 kernel.
+    Every row equals the same row computed by a small launch that the 128 x 128 kernel takes (a row must not depend on the kernel
+    that computed it - the bias is the accumulators' initial value in both), with bias, with and without an activation."""
+    from tdc_video_amd import lib as L
+    L_ACT_NONE, L_ACT_GELU_ERF = L.ACT_NONE, L.ACT_GELU_ERF
+    g = torch.Generator(device="cuda").manual_seed(13)
+    N, K = 1280, 192
+    M = 256 * 40 + 77                                   # 41 x 5 = 205 tiles of 256 x 256 (>= 192: the 256 x 256 path)
+    nseg = (M + seg - 1) // seg
+    rows = max((nseg - 1) * stride + off + seg, nseg * stride + off) + 1
+    a = torch.randn(rows, K, device="cuda", generator=g).to(dtype)
+    w = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).to(dtype)
+    bias = 3 * torch.randn(N, device="cuda", generator=g)
+    m = torch.arange(M, device="cuda")
+    src = (m // seg) * stride + off + (m % seg)
+    for act in (L_ACT_NONE, L_ACT_GELU_ERF):
+        out = ops.gemm(a, w, bias, act=act, M=M, a_map=(seg, stride, off, 1))
+        lin = a[src].float() @ w.float().t() + bias
+        ref = F.gelu(lin) if act == L_ACT_GELU_ERF else lin
+        assert relerr(out, ref) < tol(dtype)
+        for lo in (0, 256 * 17 + 5, M - 130):           # the same rows through a launch of < 192 tiles: the 128 x 128 kernel
+            n = 130
+            sub = ops.gemm(a[src[lo:lo + n]].contiguous(), w, bias, act=act)
+            assert torch.equal(sub, out[lo:lo + n])
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_large_bias_as_initial_accumulator_value(ops, dtype):
+    """The bias is the accumulators' initial value (round 5): b + sum instead of sum + b.  With |b| three orders of magnitude above
+    the products the fp32 accumulation loses the low bits of every partial sum to the large accumulator (K / 32 = 48 MFMA steps at
+    the magnitude of b, each good to ~2^-22 of it) - bounded here against the fp64 result: fp32 output within 4e-6 of |b| (measured
+    2.4e-6; "sum + b" would be 20 x closer, which no 16-bit operand or output of this path can see), 16-bit output within its own ulp."""
+    g = torch.Generator(device="cuda").manual_seed(17)
+    M, N, K = 256 * 30, 1792, 1536                      # 210 tiles: the persistent kernel
+    a = torch.randn(M, K, device="cuda", generator=g).to(dtype)
+    w = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).to(dtype)
+    bias = 1000.0 * (1 + torch.rand(N, device="cuda", generator=g))
+    ref = a.double() @ w.double().t() + bias.double()
+    out32 = ops.gemm(a, w, bias, out_f32=True)
+    e32 = ((out32.double() - ref).abs() / ref.abs()).max().item()
+    print("large bias, fp32 output: %.2e of |ref|" % e32)
+    assert e32 < 4e-6
+    out16 = ops.gemm(a, w, bias)
+    ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    assert ((out16.double() - ref).abs() / ref.abs()).max().item() < 0.6 * ulp
+
+
+@pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("cols", [48, 64, 768, 1024, 1152, 1536, 3584])
 def test_layernorm(ops, dtype, cols):
     g = torch.Generator(device="cuda").manual_seed(3)
