@@ -244,41 +244,20 @@ __global__ __launch_bounds__(256, (QT <= 2 ? 2 : 1)) void attn_kernel(AttnArgs p
             const float m_use = (BIAS && m_new == -INFINITY) ? 0.f : m_new;
             const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_use);
             m_run[t] = m_new;
-#ifdef ATTN16_PACKED      // rounds 1-4: exponent arguments and row sums on register pairs (v_pk_fma_f32 / v_pk_add_f32)
             const f32x4 nm4 = {-m_use, -m_use, -m_use, -m_use};
             f32x4 rs4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                const f32x4 z = BIAS ? s[t][kt] + nm4 : __builtin_elementwise_fma(s[t][kt], c4, nm4);
+                const f32x4 z = BIAS ? s[t][kt] + nm4 : __builtin_elementwise_fma(s[t][kt], c4, nm4);   // v_pk_fma_f32
                 f32x4 e;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(z[r]);
                 const typename VecOf<T>::v4 e16 = cvt4<T>(e);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pf[t][kt >> 1][(kt & 1) * 4 + r] = e16[r];
-                rs4 += e;
+                rs4 += e;                                                       // v_pk_add_f32
             }
             const float rs = (rs4[0] + rs4[1]) + (rs4[2] + rs4[3]);
-#else                     // single-value arithmetic, the same four partial sums: packed fp32 never runs beside the partner wave's
-                          // MFMAs (attention32.hip, round 5)
-            const float nm = -m_use;
-            float rsv[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                f32x4 e;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float z = BIAS ? s[t][kt][r] + nm : __builtin_fmaf(s[t][kt][r], p.scale_log2, nm);
-                    asm volatile("" : "+v"(z));
-                    e[r] = __builtin_amdgcn_exp2f(z);
-                    rsv[r] += e[r];
-                }
-                const typename VecOf<T>::v4 e16 = cvt4<T>(e);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pf[t][kt >> 1][(kt & 1) * 4 + r] = e16[r];
-            }
-            const float rs = (rsv[0] + rsv[1]) + (rsv[2] + rsv[3]);
-#endif
             l_run[t] = l_run[t] * alpha + rs;
             // the running max only moves in the first few tiles: skip the O rescale when no lane's max changed
             if (!__all(alpha == 1.0f)) {
