@@ -118,6 +118,61 @@ def random_state_dict(H, K, device, gen, siglip_px=384, dino_pos_grid=37, std=0.
     return sd
 
 
+def build_mixin_lm(cfg, sd, dev, dtype, extra=None, vocab=2048):
+    """The drop-in boundary around the same weights (`--via-mixin`, tests): a stub language model - `config`, `embed_tokens`,
+    `dtype`, nothing else; the LLM is stubbed in every BASELINE config - hosting tdc-video_amd/model.py's CambrianMetaModel /
+    CambrianMetaForCausalLM exactly as CambrianQwenForCausalLM hosts the reference's mixins
+    (/root/reference/tdc/language_model/cambrian_qwen.py:205-232), its parameters loaded from `sd` (reference names).
+    cfg: model_cfg(...) dict; extra: the non-reference keys (tdc_frame_cap, tdc_tower_dtype, ...)."""
+    import types
+    import torch.nn as nn
+    import tdc_video_amd  # noqa: F401
+    from tdc_video_amd.model import CambrianMetaForCausalLM, CambrianMetaModel
+    ns = types.SimpleNamespace(mm_vision_tower_aux_list=["siglip/CLIP-ViT-SO400M-14-384", "facebook/dinov2-giant-res378"],
+                               mm_projector_type="sva", connector_only=True, tokenizer_padding_side="right", **cfg)
+    for k, v in (extra or {}).items():
+        setattr(ns, k, v)
+
+    class StubBase(nn.Module):
+        def __init__(self, config):
+            super().__init__()
+            self.config = config
+            self.embed_tokens = nn.Embedding(vocab, config.hidden_size)
+
+        @property
+        def dtype(self):
+            return dtype
+
+    class StubModel(CambrianMetaModel, StubBase):
+        pass
+
+    class StubLM(nn.Module, CambrianMetaForCausalLM):
+        def __init__(self, config):
+            nn.Module.__init__(self)
+            self.config = config
+            self.model = StubModel(config)
+
+        def get_model(self):
+            return self.model
+    with torch.device(dev):
+        lm = StubLM(ns)
+        for t in lm.model.vision_tower_aux_list:
+            t.load_model()
+    m = lm.model
+    missing, unexpected = m.load_state_dict({k: v for k, v in sd.items() if not k.startswith("vision_tower_aux_list")},
+                                            strict=False)
+    assert not unexpected, unexpected[:5]
+    for i, t in enumerate(m.vision_tower_aux_list):
+        pre = "vision_tower_aux_list.%d.vision_tower." % i
+        tsd = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+        if i == 1 and "embeddings.position_embeddings" in tsd:      # the stub allocates DINOv2's 37 x 37 table (518 px)
+            assert tsd["embeddings.position_embeddings"].shape == t.vision_tower.state_dict()["embeddings.position_embeddings"].shape
+        miss, unexp = t.vision_tower.load_state_dict(tsd, strict=False)
+        assert not unexp and not miss, (miss[:3], unexp[:3])
+    m.embed_tokens.to(device=dev, dtype=dtype)
+    return lm
+
+
 def synth_video(lo, hi, px, device, dtype, seed=1234, scene_len=21):
     """frames [lo, hi) of a deterministic synthetic video (scene = constant base image + per-frame noise)."""
     g = torch.Generator(device=device)
@@ -199,7 +254,7 @@ def pmc_leg(gemms, budget_s, H, live_gemm_ms):
             return None
         os.makedirs(os.path.dirname(binary), exist_ok=True)
         r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-o", binary, os.path.join(ROOT, "tools", "gemm_pmc.cpp"),
-                            "-L" + os.path.join(ROOT, "tdc-video_amd"), "-ltdc_hip", "-Wl,-rpath," + os.path.join(ROOT, "tdc-video_amd")],
+                            "-L" + os.path.join(ROOT, "tdc-video_amd"), "-ltdc_hip", "-Wl,-rpath,$ORIGIN/../../tdc-video_amd"],
                            capture_output=True, text=True)
         if r.returncode != 0:
             sys.stderr.write("bench.py: building tools/bin/gemm_pmc failed: %s\n" % r.stderr[-300:])
@@ -328,6 +383,8 @@ def main():
                     help="the towers' residual stream in HBM: fp16 (default; the reference's own arithmetic - its HF towers run "
                          "under torch_dtype=float16 - 4 B per element and residual add, sums formed in fp32 and rounded once) or fp32 "
                          "(8 B per element: rounds 1-3)")
+    ap.add_argument("--dino-dtype", default="", choices=["", "bf16", "fp16"], help="operand type of the DINOv2 tower alone "
+                    "(config.tdc_dino_dtype; default: the towers' type): fp16 keeps the a5 similarities at the reference's precision")
     ap.add_argument("--px", type=int, default=384, help="SigLIP input size (DINO uses px-6: 378); 336 -> 336/336")
     ap.add_argument("--fp8-level", type=int, default=1, choices=[1, 2, 3],
                     help="--dtype fp8: 1 = qkv / fc1 (quantised by the LayerNorm kernel), 2 = also out-proj / fc2, "
@@ -357,6 +414,11 @@ def main():
                     "default 600 + 4 x (steps + warmup): a step takes 1.2 s at T = 512 on one GPU)")
     ap.add_argument("--collective-timeout", type=float, default=180.0, help="N > 1: timeout of the process group (rendezvous and "
                     "every collective) in seconds")
+    ap.add_argument("--via-mixin", action="store_true", help="drive the step through the drop-in boundary instead of VideoEncoder: "
+                    "a stub language model hosting model.CambrianMetaForCausalLM, one call of prepare_inputs_labels_for_multimodal("
+                    "input_ids, ..., images=[siglip[1,T,...], dino[1,T,...]], image_sizes, video_indices=[None], prompts=[ids]) per "
+                    "step with config.tdc_frame_cap = T (N > 1: + config.tdc_shard_frames, every rank holds the whole video as the "
+                    "reference's eval workers do); the JSON line says config.entry = \"mixin\"")
     ap.add_argument("--dump-gemm-shapes", default=None, help="write the GEMM launches of one step (for tools/gemm_pmc)")
     args = ap.parse_args()
     for k in ("launch_timeout", "rank_timeout"):
@@ -403,12 +465,29 @@ def main():
     cfg = model_cfg(H, K, T)
     gen = torch.Generator(device=dev).manual_seed(0)
     sd = random_state_dict(H, K, dev, gen, siglip_px=px_s)
-    enc = VideoEncoder(sd, cfg, dtype=dtype, device=dev, siglip_heads=16, dino_heads=24, qformer_heads=12,
-                       tower_batch=args.tower_batch, fp8_towers=args.fp8_level if args.dtype == "fp8" else 0,
-                       tower_dtype=tower_dtype,
-                       tower_res_dtype=torch.float16 if (args.res == "fp16" and args.dtype != "fp8") else None)
     two_streams = args.two_streams if args.two_streams >= 0 else int((T + world - 1) // world <= 128)
-    enc.two_streams = bool(two_streams)
+    res16 = args.res == "fp16" and args.dtype != "fp8"
+    product_setting = {"dtype": str(dtype).replace("torch.", ""), "tdc_tower_dtype": str(tower_dtype).replace("torch.", ""),
+                       "tdc_tower_res_dtype": "float16" if res16 else "float32", "tdc_tower_batch": args.tower_batch,
+                       "tdc_fp8_towers": args.fp8_level if args.dtype == "fp8" else 0, "tdc_frame_cap": T,
+                       "tdc_two_streams": bool(two_streams)}
+    if args.dino_dtype:
+        product_setting["tdc_dino_dtype"] = {"bf16": "bfloat16", "fp16": "float16"}[args.dino_dtype]
+    lm = None
+    if args.via_mixin:
+        if args.audio or args.recompute_halo:
+            sys.exit("bench.py: --via-mixin covers the video path (no --audio / --recompute-halo)")
+        extra = {k: v for k, v in product_setting.items() if k != "dtype"}
+        if world > 1:
+            extra["tdc_shard_frames"] = True
+        lm = build_mixin_lm(cfg, sd, dev, dtype, extra)
+        enc = lm.get_model().tdc_engine(device=dev, dtype=dtype)       # built by the mixin from its own parameters
+    else:
+        enc = VideoEncoder(sd, cfg, dtype=dtype, device=dev, siglip_heads=16, dino_heads=24, qformer_heads=12,
+                           tower_batch=args.tower_batch, fp8_towers=args.fp8_level if args.dtype == "fp8" else 0,
+                           tower_dtype=tower_dtype, tower_res_dtype=torch.float16 if res16 else None,
+                           dino_dtype={"bf16": torch.bfloat16, "fp16": torch.float16, "": None}[args.dino_dtype])
+        enc.two_streams = bool(two_streams)
     enc.xattn_mode = args.xattn_mode
     wav = None
     if args.audio:
@@ -431,7 +510,21 @@ def main():
 
     prompt_ids = [101] + list(range(2000, 2010)) + [102]          # 12 BERT ids
     lo, hi = seg.shard_ranges(T, world)[rank]
-    if world == 1:
+    if lm is not None:
+        # the reference's call (tdc/language_model/cambrian_qwen.py:415-438): one sample, <image> after the system prompt,
+        # 64 text tokens; every rank is handed the whole video, as the reference's per-GPU eval workers are
+        vs = synth_video(0, T, px_s, dev, tower_dtype)
+        vd = synth_video(0, T, px_d, dev, tower_dtype, seed=4321) if px_d != px_s else vs
+        ids = torch.arange(100, 165, device=dev)
+        ids[14] = -200                                                  # IMAGE_TOKEN_INDEX (tdc/constants.py)
+        ids = ids[None]
+        images = [vs[None], vd[None]]
+
+        def step():
+            o = lm.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, images, image_sizes=[(384, 384)],
+                                                        video_indices=[None], prompts=[prompt_ids], audios=[None])
+            return o[4][0]
+    elif world == 1:
         vs = synth_video(0, T, px_s, dev, tower_dtype)
         vd = synth_video(0, T, px_d, dev, tower_dtype, seed=4321) if px_d != px_s else vs
 
@@ -564,7 +657,7 @@ def main():
     step_tf = (g_fl + a_fl + x_fl) / (ms_per_step * 1e-3) / 1e12 * (world if world > 1 else 1)
     roofline = dict(bound="mfma", achieved=round(achieved, 1), peak=peak, unit="TFLOP/s",
                     frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_source,
-                    kernel="gemm256p_kernel / gemm256_kernel / gemm_kernel (tdc_gemm)",
+                    kernel="gemm256p_kernel / gemm_kernel (tdc_gemm)",
                     launches=len(gemms), avg_launch_us=round(g_ms * 1e3 / max(1, len(gemms)), 2),
                     host_path="C++ composites (tdc_vit_fwd / tdc_connector_fwd / tdc_qformer_fwd): the path of the timed steps; "
                               "events recorded inside libtdc_hip.so (tdc_profile_*)",
@@ -609,12 +702,11 @@ def main():
                                   "the Q-Former KV)" % T if args.audio else ""),
                    "frames": T, "K": K, "hidden": H, "px": px_s, "tower_residual": args.res if args.dtype != "fp8" else "fp32",
                    # the model-level settings (tdc-video_amd/model.py: CambrianMetaModel.tdc_engine) that build this encoder
-                   "product_setting": {"dtype": str(dtype).replace("torch.", ""), "tdc_tower_dtype": str(tower_dtype).replace("torch.", ""),
-                                       "tdc_tower_res_dtype": "float16" if (args.res == "fp16" and args.dtype != "fp8") else "float32",
-                                       "tdc_tower_batch": args.tower_batch,
-                                       "tdc_fp8_towers": args.fp8_level if args.dtype == "fp8" else 0},
+                   "product_setting": product_setting,
+                   "entry": "mixin: CambrianMetaForCausalLM.prepare_inputs_labels_for_multimodal on a stub LM (value counts its text "
+                            "splice and padding too)" if lm is not None else "engine: VideoEncoder.encode_video",
                    "parallelism": "frames sharded over %d GPU(s)" % world, "two_streams": bool(two_streams),
-                   "emitted_tokens": int(out.shape[0])},
+                   "emitted_tokens": int(out.shape[0]) - (64 if lm is not None else 0)},
         "rank_ms_per_step": None if rank_ms is None else {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
         "ranks_seen": ranks_seen, "rank_devices": rank_devices if world > 1 else [local],
         "dist_backend": (os.environ.get("TDC_DIST_BACKEND", "nccl") + " (RCCL)" * (os.environ.get("TDC_DIST_BACKEND", "nccl") == "nccl")) if world > 1 else None,

@@ -349,35 +349,87 @@ class CambrianMetaModel:
 
     def tdc_engine(self, device=None, dtype=None, refresh=False):
         """Build (once) the VideoEncoder from the current parameters: pads / fuses / uploads the weights.
-        `config.tdc_fp8_towers = True` / 2 / 3 (not a reference key) selects e4m3 operands for the towers' qkv / fc1 GEMMs
-        (2: out-proj / fc2 as well; 3: fc1 also writes the e4m3 MLP hidden itself; DESIGN.md §4c);
-        `config.tdc_tower_dtype = "bfloat16" | "float16"` (not a reference key either) runs the two ViT towers in that type
-        under a connector / Q-Former in `dtype` (VideoEncoder.tower_dtype);
-        `config.tdc_tower_res_dtype = "float16" (default) | "bfloat16" | "float32"`: the towers' residual stream in HBM
-        (VideoEncoder.tower_res_dtype).  fp16 is the reference's own arithmetic - its HF towers run under
-        torch_dtype=float16, tdc/builder.py:69 - and what bench.py measures; fp8 towers keep the fp32 stream;
-        `config.tdc_tower_batch` (default 64, the reference's own chunk, tdc/cambrian_arch.py:698-745): frames per tower batch.
+        Keys that are not reference keys (all optional; INTEGRATION.md lists them):
+        `config.tdc_fp8_towers = True` / 2 / 3 selects e4m3 operands for the towers' qkv / fc1 GEMMs (2: out-proj / fc2 as
+        well; 3: fc1 also writes the e4m3 MLP hidden itself) - a throughput mode, not a parity mode;
+        `config.tdc_tower_dtype = "bfloat16" | "float16"`: GEMM operand type of the two ViT towers under a connector / Q-Former
+        in `dtype`; `config.tdc_dino_dtype`: the same for the DINOv2 tower alone (it alone drives the a5 segment selection,
+        tdc/cambrian_arch.py:832-849: "float16" there keeps the similarities at the reference's own precision under a bf16
+        SigLIP tower);
+        `config.tdc_tower_res_dtype = "float16" | "bfloat16" | "float32"`: the towers' residual stream in HBM.  Default:
+        "float16" when the towers' operands are fp16 - the reference's own arithmetic, its HF towers run under
+        torch_dtype=float16 (tdc/builder.py:69) -, "float32" otherwise (bf16 operands reach 3e38, an fp16 stream ends at 65504:
+        that combination - what bench.py measures - is opt-in); fp8 towers keep the fp32 stream;
+        `config.tdc_tower_batch`: frames per tower batch; default: every frame of the call up to 512, bounded by the free HBM
+        (VideoEncoder.auto_tower_batch; the result does not depend on it bit for bit, the reference's own chunk is 64,
+        tdc/cambrian_arch.py:698-745);
+        `config.tdc_frame_cap` (default 224 = the reference's "in case of OOM" constant, tdc/cambrian_arch.py:907-916,813-822):
+        the cap of both frame sub-samplings; `config.tdc_shard_frames`: see prepare_inputs_labels_for_multimodal.
         bench.py's line is reproduced by dtype=float16, tdc_tower_dtype="bfloat16", tdc_tower_res_dtype="float16",
-        tdc_tower_batch=512 (its `product_setting` field says so)."""
+        tdc_frame_cap=T (its `product_setting` field says so; `bench.py --via-mixin` runs exactly that)."""
         if self._tdc_encoder is None or refresh:
             cfg = {k: getattr(self.config, k) for k in dir(self.config)
                    if not k.startswith("_") and isinstance(getattr(self.config, k, None), (int, float, str, bool, list))}
             device = device or ("cuda:%d" % torch.cuda.current_device())
             dtype = dtype or (self.dtype if self.dtype in (torch.float16, torch.bfloat16) else torch.float16)
             towers = self.vision_tower_aux_list
+            fp8 = int(cfg.get("tdc_fp8_towers", 0) or 0)
+            tower_dtype = _dtype_key(cfg, "tdc_tower_dtype", allow32=False)
+            dino_dtype = _dtype_key(cfg, "tdc_dino_dtype", allow32=False)
+            if "tdc_tower_res_dtype" in cfg:
+                res = _dtype_key(cfg, "tdc_tower_res_dtype")
+            else:
+                res = torch.float16 if (tower_dtype or dtype) == torch.float16 and (dino_dtype or tower_dtype or dtype) == \
+                    torch.float16 else None
+            tb = cfg.get("tdc_tower_batch")
+            if tb is not None and (isinstance(tb, bool) or not isinstance(tb, int) or tb < 0):
+                raise ValueError("config.tdc_tower_batch must be a positive frame count (or 0 / absent for the automatic "
+                                 "choice), got %r" % (tb,))
             self._tdc_encoder = VideoEncoder(self.tdc_state_dict(), cfg, dtype=dtype, device=device,
                                              siglip_heads=towers[0].heads, dino_heads=towers[1].heads,
-                                             qformer_heads=self._qformer_arch["heads"],
-                                             fp8_towers=int(cfg.get("tdc_fp8_towers", 0) or 0),
-                                             tower_batch=int(cfg.get("tdc_tower_batch", 64) or 64),
-                                             tower_dtype=_DT16[cfg.get("tdc_tower_dtype")],
-                                             tower_res_dtype=None if int(cfg.get("tdc_fp8_towers", 0) or 0)
-                                             else _DT16[cfg.get("tdc_tower_res_dtype", "float16")])
+                                             qformer_heads=self._qformer_arch["heads"], fp8_towers=fp8,
+                                             tower_batch=tb or None, tower_dtype=tower_dtype, dino_dtype=dino_dtype,
+                                             tower_res_dtype=None if (fp8 and not cfg.get("tdc_tower_res_dtype")) else res)
         return self._tdc_encoder
+
+    def tdc_frame_cap(self):
+        """`config.tdc_frame_cap`: the reference's constant 224 of both frame caps (tdc/cambrian_arch.py:907-916,813-822; SURVEY
+        D3) as a config key.  224 (the default) is the parity setting."""
+        cap = getattr(self.config, "tdc_frame_cap", 224)
+        if cap is None:
+            return 224
+        if isinstance(cap, bool) or not isinstance(cap, int) or cap < 1:
+            raise ValueError("config.tdc_frame_cap must be a positive frame count, got %r" % (cap,))
+        return cap
+
+    def tdc_sharded_engine(self):
+        """dist.ShardedVideoEncoder over the default process group when `config.tdc_shard_frames` is set and
+        torch.distributed runs with more than one rank (one process per GPU, RCCL); None otherwise."""
+        if not getattr(self.config, "tdc_shard_frames", False):
+            return None
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() < 2:
+            return None
+        sh = getattr(self, "_tdc_sharded", None)
+        if sh is None or sh.e is not self.tdc_engine():
+            from .dist import ShardedVideoEncoder
+            sh = self._tdc_sharded = ShardedVideoEncoder(self.tdc_engine(), dist.get_rank(), dist.get_world_size())
+        return sh
 
 
 _DT16 = {"bfloat16": torch.bfloat16, "bf16": torch.bfloat16, "float16": torch.float16, "fp16": torch.float16,
-         "float32": None, "fp32": None, None: None}
+         "half": torch.float16, "float32": None, "fp32": None, "float": None, None: None}
+
+
+def _dtype_key(cfg, key, allow32=True):
+    """config string -> torch dtype (None = fp32 / not given), with an error that names the key and the accepted values."""
+    v = cfg.get(key)
+    if isinstance(v, torch.dtype):
+        v = str(v).replace("torch.", "")
+    if v not in _DT16 or (not allow32 and v is not None and _DT16[v] is None):
+        ok = sorted(k for k in _DT16 if k is not None and (allow32 or _DT16[k] is not None))
+        raise ValueError("config.%s = %r is not one of %s" % (key, v, ok))
+    return _DT16[v]
 
 
 class CambrianMetaForCausalLM(ABC):
@@ -436,7 +488,7 @@ class CambrianMetaForCausalLM(ABC):
             if T <= max_num_segments + 1:
                 idx, segi = list(range(T)), list(range(T))
             else:
-                idx = seg.uniform_indices(T, 224)
+                idx = seg.uniform_indices(T, self.get_model().tdc_frame_cap())     # :813-822 (config.tdc_frame_cap)
                 ff = f[idx] if len(idx) != T else f
                 P, D = ff.shape[1], ff.shape[2]
                 flat = ff.reshape(len(idx) * P, D).contiguous()
@@ -467,6 +519,11 @@ class CambrianMetaForCausalLM(ABC):
         H = model.config.hidden_size
         is_video = type(images[0]) is list or images[0].ndim == 5
         bsz = input_ids.shape[0]
+        # every integer decision below (text lengths, <image> positions, which rows survive the mask) is taken on ONE host copy of
+        # the ids / mask: a device-side torch.where(...).tolist() waits for everything queued on the stream - the previous
+        # video's encode when calls follow each other
+        ids_host = input_ids.detach().cpu()
+        mask_host = None if attention_mask is None else attention_mask.detach().cpu().bool()
         visual = []          # per sample: [n_tokens, H] tensor on the engine device
         spliced = []         # per sample: `visual[i]` already holds the text rows around the visual tokens
         final_size = []
@@ -477,9 +534,9 @@ class CambrianMetaForCausalLM(ABC):
                     vid_s, vid_d = vid_s.unsqueeze(0), vid_d.unsqueeze(0)
             else:
                 vid_s, vid_d = images[0][i:i + 1], images[1][i:i + 1]
-            cur_ids = input_ids[i]
-            if attention_mask is not None:
-                cur_ids = cur_ids[attention_mask[i].bool() | (cur_ids == IMAGE_TOKEN_INDEX)]
+            cur_ids = ids_host[i]
+            if mask_host is not None:
+                cur_ids = cur_ids[mask_host[i] | (cur_ids == IMAGE_TOKEN_INDEX)]
             n_text = int((cur_ids != IMAGE_TOKEN_INDEX).sum())
             prompt_ids = None
             if is_video and cfgd.get("text_input", True):
@@ -517,15 +574,37 @@ class CambrianMetaForCausalLM(ABC):
                 # video_indices[i]: 0/1 per second of audio, 1 where a frame was decoded (cambrian_arch.py:916-926); [None]
                 # (what generate() passes) / None: input frame t is second t
                 vindex = video_indices[i] if video_indices is not None and i < len(video_indices) else None
-                vis = eng.encode_video(vid_s.to(eng.dev), vid_d.to(eng.dev), tuple(image_sizes[i]),
-                                       budget_text_len=self._budget_text_len(input_ids[i]), n_text_tokens=n_text,
-                                       prompt_ids=prompt_ids, audio=audio, keep=keep, splice=splice, video_index=vindex)
+                cap = model.tdc_frame_cap()
+                btl = self._budget_text_len(ids_host[i])
+                sharded = model.tdc_sharded_engine()
+                if sharded is not None:
+                    # config.tdc_shard_frames under an initialised torch.distributed (one process per GPU, every rank called
+                    # with the same video - how the reference's eval drivers start their workers, eval/eval_mlvu.py:129-157 -
+                    # but here the ranks split the FRAMES of the one video): this rank encodes frames [lo, hi) of the a1
+                    # selection, dist.ShardedVideoEncoder exchanges what crosses the rank boundaries and all-gathers the
+                    # emitted tokens, so every rank returns the same 10-tuple as the serial path, bit for bit
+                    fp = sharded.frame_plan(vid_s.shape[0], btl, cap, vindex)
+                    ts = getattr(model.config, "tdc_two_streams", None)
+                    eng.two_streams = bool(ts) if ts is not None else (fp["hi"] - fp["lo"]) <= 128
+                    sel_s = torch.as_tensor(fp["siglip_frames"], dtype=torch.long, device=vid_s.device)
+                    sel_d = torch.as_tensor(fp["dino_frames"], dtype=torch.long, device=vid_d.device)
+                    vis = sharded.encode_video(vid_s[sel_s].to(eng.dev), vid_d[sel_d].to(eng.dev), fp["T"],
+                                               tuple(image_sizes[i]), n_text, prompt_ids, audio=audio,
+                                               sample_indices=fp["sample_indices"])
+                    keep["final_size"] = [seg.unpad_newline_map(eng.side, tuple(image_sizes[i]), 0)[1]] * fp["T"]
+                    splice = None
+                else:
+                    ts = getattr(model.config, "tdc_two_streams", None)
+                    eng.two_streams = bool(ts) if ts is not None else min(vid_s.shape[0], cap) <= 128
+                    vis = eng.encode_video(vid_s.to(eng.dev), vid_d.to(eng.dev), tuple(image_sizes[i]),
+                                           budget_text_len=btl, n_text_tokens=n_text, prompt_ids=prompt_ids, audio=audio,
+                                           frame_cap=cap, info=keep, splice=splice, video_index=vindex)
                 spliced.append(splice is not None)
             else:
                 # single images: every image is a static frame, no segmentation / Q-Former (cambrian_arch.py:980-983)
                 sig = eng.tower("siglip", vid_s.to(eng.dev))
                 dino = eng.tower("dino", vid_d.to(eng.dev))
-                X, sizes = eng.connector(sig, dino, 1, [tuple(image_sizes[i])], keep)
+                X, sizes = eng.connector(sig, dino, 1, [tuple(image_sizes[i])])
                 vis = X[:, :H]
                 keep["final_size"] = sizes
             if not is_video:
@@ -543,12 +622,17 @@ class CambrianMetaForCausalLM(ABC):
         if labels is None:
             labels = torch.full_like(input_ids, IGNORE_INDEX)
         attention_mask = attention_mask | (input_ids == IMAGE_TOKEN_INDEX)
+        keep_host = torch.ones_like(ids_host, dtype=torch.bool) if mask_host is None else \
+            (mask_host | (ids_host == IMAGE_TOKEN_INDEX))
         embed = model.embed_tokens
         new_embeds, new_labels = [], []
         for i in range(bsz):
-            ids = input_ids[i][attention_mask[i]]
-            lab = labels[i][attention_mask[i]]
-            img_pos = torch.where(ids == IMAGE_TOKEN_INDEX)[0].tolist()
+            if bool(keep_host[i].all()):
+                ids, lab, ids_h = input_ids[i], labels[i], ids_host[i]
+            else:           # integer row indices made on the host: a boolean mask on the device would wait for its own count
+                rows = torch.nonzero(keep_host[i])[:, 0]
+                ids, lab, ids_h = input_ids[i][rows.to(input_ids.device)], labels[i][rows.to(labels.device)], ids_host[i][rows]
+            img_pos = torch.where(ids_h == IMAGE_TOKEN_INDEX)[0].tolist()
             vis = visual[i]
             if not img_pos:
                 new_embeds.append(torch.cat([embed(ids), vis[0:0].to(embed.weight.dtype)], 0))
@@ -584,14 +668,17 @@ class CambrianMetaForCausalLM(ABC):
         pos = torch.zeros((bsz, max_len), dtype=position_ids.dtype, device=position_ids.device)
         for i, (e, l) in enumerate(zip(new_embeds, new_labels)):
             n = e.shape[0]
-            z = torch.zeros((max_len - n, e.shape[1]), dtype=e.dtype, device=e.device)
-            emb_pad.append(torch.cat((z, e), 0) if left else torch.cat((e, z), 0))
+            if n == max_len:            # nothing to pad (always so for one sample): no 2 x 650-MB copy of a T = 512 stream
+                emb_pad.append(e)
+            else:
+                z = torch.zeros((max_len - n, e.shape[1]), dtype=e.dtype, device=e.device)
+                emb_pad.append(torch.cat((z, e), 0) if left else torch.cat((e, z), 0))
             if n > 0:
                 sl = slice(max_len - n, max_len) if left else slice(0, n)
                 lab_pad[i, sl] = l
                 att[i, sl] = True
                 pos[i, sl] = torch.arange(0, n, dtype=pos.dtype, device=pos.device)
-        new_input_embeds = torch.stack(emb_pad, 0)
+        new_input_embeds = emb_pad[0].unsqueeze(0) if bsz == 1 else torch.stack(emb_pad, 0)
         new_labels_out = None if _labels is None else lab_pad
         att_out = None if _attention_mask is None else att.to(dtype=_attention_mask.dtype)
         pos_out = None if _position_ids is None else pos

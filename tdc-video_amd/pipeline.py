@@ -48,16 +48,23 @@ class _LRU(dict):
 
 class VideoEncoder:
     def __init__(self, sd, cfg, dtype=torch.float16, device="cuda", siglip_heads=16, dino_heads=24,
-                 qformer_heads=12, tower_batch=64, fp8_towers=False, tower_dtype=None, ln_fuse=False,
-                 tower_res_dtype=None):
+                 qformer_heads=12, tower_batch=None, fp8_towers=False, tower_dtype=None, ln_fuse=False,
+                 tower_res_dtype=None, dino_dtype=None):
         """sd: reference-named state dict without the leading 'model.'; cfg: dict of reference config keys.
         dtype: 16-bit type of the connector, the Q-Former and every tensor handed to the caller; tower_dtype (default:
         dtype): 16-bit type of the two ViT towers - their last kernel (the token-grid resample) writes `dtype` rows.  bf16
         towers under an fp16 connector / compressor keep the compressed tokens within 1e-3 of the fp32 reference arithmetic (measured
         1.0e-4 at full depth; all-bf16: 6e-4 ... 2e-3): the 16-bit error of the context tokens is made behind the towers.
+        dino_dtype (default: tower_dtype): operand type of the DINOv2 tower alone.  Its features alone drive the a5 segment
+        selection (tdc/cambrian_arch.py:832-849): fp16 there keeps the adjacent-frame similarities at the reference's own
+        precision (3.4e-5 instead of 4.2e-4 with bf16 operands) while SigLIP stays in tower_dtype.
         fp8_towers (BASELINE config 5): the towers' LayerNorms emit e4m3 rows with per-row scales and the qkv / fc1 GEMMs
         run on fp8 operands (v_mfma_f32_16x16x128_f8f6f4); everything else stays in `tower_dtype`.
         ln_fuse: the towers' pre-LayerNorms folded into the neighbouring GEMMs (weights.ln_fusion_enabled; off by default).
+        tower_batch: frames per tower launch sequence; None (default) = all frames of the call up to TOWER_BATCH_MAX, halved
+        until the tower workspace fits the free HBM (`auto_tower_batch`) - the result does not depend on it, bit for bit
+        (tests: test_batch_invariance_and_determinism), the rate does (512 / 256 / 128 / 64 frames: 428.8 / 425.7 / 420.1 /
+        407.6 frames/s, profiles/r04_tower_batch.log).  The reference's own chunk is 64 (tdc/cambrian_arch.py:698-745).
         tower_res_dtype: type of the towers' residual stream in HBM - None / torch.float32: fp32 (the out-projection / fc2
         epilogues read-modify-write 8 B per element); torch.float16 (or bfloat16): that 16-bit type - 4 B per element, half
         the LayerNorm input bytes, sums formed in fp32 and rounded once per residual add.  fp16 is the reference's own
@@ -76,7 +83,10 @@ class VideoEncoder:
         if s_sd:
             self.towers["siglip"] = Wt.prep_siglip(s_sd, siglip_heads, tower_dtype, self.dev, fp8=fp8_towers, ln_fuse=ln_fuse)
         if d_sd:
-            self.towers["dino"] = Wt.prep_dino(d_sd, dino_heads, tower_dtype, self.dev, fp8=fp8_towers, ln_fuse=ln_fuse)
+            self.towers["dino"] = Wt.prep_dino(d_sd, dino_heads, dino_dtype or tower_dtype, self.dev, fp8=fp8_towers,
+                                               ln_fuse=ln_fuse)
+        for t in self.towers.values():
+            t["dtype"] = dino_dtype or tower_dtype if t.kind == "dino" else tower_dtype
         self.c = Wt.prep_connector(sd, cfg, dtype, self.dev)
         tok = cfg.get("mm_vision_tower_aux_token_len_list", [576, 576])
         self.out_grid = [int(round(t ** 0.5)) for t in tok]
@@ -97,6 +107,10 @@ class VideoEncoder:
     def tower_dtype(self):
         return self.__dict__.get("_tower_dtype") or self.dtype
 
+    def _tdt(self, t):
+        """operand type of tower `t` (its weights' type): tower_dtype unless dino_dtype set the DINOv2 tower apart"""
+        return t.get("dtype") or self.tower_dtype
+
     # ------------------------------------------------------------------------------------------------ towers
     def _bil(self, n_in, n_out):
         key = (n_in, n_out)
@@ -109,9 +123,34 @@ class VideoEncoder:
         t = self.towers[name]
         out_grid = self.out_grid[0 if name == "siglip" else 1]
         outs = []
-        for s in range(0, px.shape[0], self.tower_batch):
-            outs.append(self._tower_batch(t, px[s:s + self.tower_batch].contiguous(), out_grid))
+        tb = int(self.tower_batch) if self.tower_batch else self.auto_tower_batch(t, px)
+        for s in range(0, px.shape[0], tb):
+            outs.append(self._tower_batch(t, px[s:s + tb].contiguous(), out_grid))
         return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+
+    TOWER_BATCH_MAX = 512      # the largest batch measured (profiles/r04_tower_batch.log); one 512-frame batch needs ~15 GB
+
+    def auto_tower_batch(self, t, px, free_bytes=None):
+        """Frames per tower batch when the caller gave none: min(frames, TOWER_BATCH_MAX), halved until tdc_vit_workspace_bytes
+        fits 60 % of the HBM this process can still get (free on the device + what torch's allocator holds unused + the
+        workspace it would replace).  free_bytes: override of that figure (tests)."""
+        import ctypes as C
+        B = max(1, min(int(px.shape[0]), self.TOWER_BATCH_MAX))
+        if len(t.layers) == 0 or not px.is_cuda:
+            return B
+        Hpx, Wpx = int(px.shape[2]), int(px.shape[3])
+        m = self._vit_struct(t, Hpx // t.patch, Wpx // t.patch)[0]
+        lib = L.load()
+        if free_bytes is None:
+            free, _total = torch.cuda.mem_get_info(self.dev)
+            unused = torch.cuda.memory_reserved(self.dev) - torch.cuda.memory_allocated(self.dev)
+            wkey = "_vit_ws_" + t.kind if getattr(self, "two_streams", False) else "_vit_ws"
+            ws = getattr(self, wkey, None)
+            free_bytes = free + max(0, unused) + (ws.numel() if ws is not None else 0)
+        budget = 0.6 * free_bytes
+        while B > 1 and lib.tdc_vit_workspace_bytes(C.byref(m), B, Hpx, Wpx) > budget:
+            B = (B + 1) // 2
+        return B
 
     # ---- native composite (csrc/api.cpp: tdc_vit_fwd): the whole tower batch is one C call ------------------------------
     def _vit_struct(self, t, gh, gw):
@@ -138,7 +177,7 @@ class VideoEncoder:
                                    zeros.data_ptr() if zeros is not None else None,
                                    Lr.out.wscale or 0.0, Lr.fc2.wscale or 0.0, Lr.fc1.w2max, Lr.fc1.bmax)
         m = L.VitModel()
-        m.dtype, m.out_dtype_p1 = ops._dtcode(self.tower_dtype), ops._dtcode(self.dtype) + 1
+        m.dtype, m.out_dtype_p1 = ops._dtcode(self._tdt(t)), ops._dtcode(self.dtype) + 1
         rd = getattr(self, "tower_res_dtype", None)
         m.res_dtype_p1 = 0 if rd is None else ops._dtcode(rd) + 1
         m.dim, m.heads, m.head_dim, m.n_layers, m.patch, m.has_cls = t.dim, t.heads, t.head_dim, len(t.layers), t.patch, \
@@ -173,7 +212,7 @@ class VideoEncoder:
         D = t.dim
         out = torch.empty(B * out_grid * out_grid, pad64(D), device=self.dev, dtype=self.dtype)
         i0, i1, fr = self._bil(g, out_grid)
-        f32 = ops.px_kind(px, self.tower_dtype)
+        f32 = ops.px_kind(px, self._tdt(t))
         L.check(lib.tdc_vit_fwd(C.byref(m), ops._ptr(px), f32, B, H, W, out_grid, ops._ptr(i0), ops._ptr(i1),
                                 ops._ptr(fr), ops._ptr(out), out.stride(0), ops._ptr(ws), ws.numel(), ops._stream()),
                 "tdc_vit_fwd")
@@ -185,7 +224,7 @@ class VideoEncoder:
         (`tower_res_dtype`: None = fp32, read-modify-written as 8 B per element; a 16-bit type = tdc_vit_model.res_dtype_p1)."""
         if getattr(self, "native_towers", True) and len(t.layers) > 0:
             return self._tower_batch_native(t, px, out_grid)
-        dt, dev = self.tower_dtype, self.dev
+        dt, dev = self._tdt(t), self.dev
         rd = getattr(self, "tower_res_dtype", None)
         s32 = rd is None                         # fp32 residual stream
         B = px.shape[0]
@@ -808,17 +847,21 @@ class VideoEncoder:
 
     # ------------------------------------------------------------------------------------------------ top level
     def encode_video(self, px_siglip, px_dino, image_size, budget_text_len, n_text_tokens, prompt_ids, audio=None,
-                     frame_cap=224, keep=None, splice=None, video_index=None):
+                     frame_cap=224, keep=None, splice=None, video_index=None, info=None):
         """One video: pixels -> emitted visual tokens [n, H] (S0-S10).  `budget_text_len` is the text length used by
-        get_max_num_frames (cambrian_arch.py:753-759), `n_text_tokens` the non-image token count (:1499-1505)."""
+        get_max_num_frames (cambrian_arch.py:753-759), `n_text_tokens` the non-image token count (:1499-1505).
+        frame_cap: the reference's "in case of OOM" constant 224 of BOTH caps (cambrian_arch.py:907-916 before the towers,
+        :813-822 inside adapt_segment) as a parameter.
+        keep: dict that receives every stage tensor (and makes the connector run its per-kernel form, which produces them);
+        info: dict that receives the host-side facts only (frame_indices, selected, seg_indices, final_size, n_visual) - free."""
         return encode_video_with(self, px_siglip, px_dino, image_size, budget_text_len, n_text_tokens, prompt_ids,
-                                 audio, frame_cap, keep, splice, video_index)
+                                 audio, frame_cap, keep, splice, video_index, info)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
 # Orchestration over an "engine" (VideoEncoder on GPUs; the gloo tests of dist.py plug in a CPU test double that
 # implements tower / sims_tensor / connector / with_audio / make_queries / compress_frames / emit / query_width).
-def compress_with(e, X, T, N, seg_indices, prompt_ids, max_visual_len, audio=None, keep=None, splice=None):
+def compress_with(e, X, T, N, seg_indices, prompt_ids, max_visual_len, audio=None, keep=None, splice=None, info=None):
     K = e.K
     cfg = getattr(e, "cfg", {})
     Xf, Nf = e.with_audio(X, T, N, audio)
@@ -834,6 +877,8 @@ def compress_with(e, X, T, N, seg_indices, prompt_ids, max_visual_len, audio=Non
     if keep is not None:
         keep["plan"] = plan
         keep["n_visual"] = len(pairs)
+    if info is not None:
+        info["n_visual"] = len(pairs)
     if splice is not None:
         return e.emit(Xf, comp, pairs, splice)
     return e.emit(Xf, comp, pairs)
@@ -859,7 +904,7 @@ def sample_indicator(T0, idx, video_index=None):
 
 
 def encode_video_with(e, px_siglip, px_dino, image_size, budget_text_len, n_text_tokens, prompt_ids, audio=None,
-                      frame_cap=224, keep=None, splice=None, video_index=None):
+                      frame_cap=224, keep=None, splice=None, video_index=None, info=None):
     cfg = e.cfg
     T0 = px_siglip.shape[0]
     idx = seg.uniform_indices(T0, min(seg.get_max_num_frames(budget_text_len, cfg), frame_cap))     # a1
@@ -910,8 +955,10 @@ def encode_video_with(e, px_siglip, px_dino, image_size, budget_text_len, n_text
     pid = prompt_ids if cfg.get("text_input", True) else None
     if audio is not None:                                                                           # a20
         audio = e.local_audio(audio, sample_indicator(T0, idx, video_index), T, 0, T)
-    vis = compress_with(e, X, T, N, seg_idx, pid, max_visual_len, audio, keep, splice)              # a11-a19 (+a21)
+    vis = compress_with(e, X, T, N, seg_idx, pid, max_visual_len, audio, keep, splice, info)        # a11-a19 (+a21)
     if keep is not None:
         keep.update(frame_indices=idx, selected=sel2, seg_indices=seg_idx, siglip_feat=sig, dino_feat=dino,
                     final_size=final_size, X=X)
+    if info is not None:
+        info.update(frame_indices=idx, selected=sel2, seg_indices=seg_idx, final_size=final_size)
     return vis

@@ -256,3 +256,75 @@ def test_split_plan_partitions_the_stream():
             lo, hi = ranges[r]
             assert all(row < (hi - lo) * N for k, row in pairs if k == 0)
             assert all(row < len(comp_local[r]) * K for k, row in pairs if k == 1)
+
+
+# ------------------------------------------------------------------------------------------------ through the mixin
+class MixinEngine(FakeEngine):
+    """FakeEngine with what the boundary (model.CambrianMetaForCausalLM) touches besides the stage methods: a device, the SVA
+    grid side (2 x 2 -> 2 * (2 + 1) = 6 rows per frame, consistent with `connector`'s sizes) and `encode_video`."""
+    dev = torch.device("cpu")
+    side = 2
+
+    def __init__(self, **kw):
+        super().__init__(N=6, **kw)
+
+    def connector(self, sig, dino, T, sizes, keep=None):
+        X, _ = super().connector(sig, dino, T, sizes, keep)
+        return X, [(2, 2)] * T
+
+    def encode_video(self, px_siglip, px_dino, image_size, budget_text_len, n_text_tokens, prompt_ids, audio=None,
+                     frame_cap=224, keep=None, splice=None, video_index=None, info=None):
+        return pipeline.encode_video_with(self, px_siglip, px_dino, image_size, budget_text_len, n_text_tokens, prompt_ids,
+                                          audio, frame_cap, keep, splice, video_index, info)
+
+
+def _mixin_call(shard, T0=90, cap=37):
+    """prepare_inputs_labels_for_multimodal on a stub LM whose engine is the CPU double; config.tdc_frame_cap lifts /
+    lowers both frame caps, config.tdc_shard_frames routes through dist.ShardedVideoEncoder when a process group exists."""
+    from test_host_logic import build_stub_lm, tiny_config
+    torch.manual_seed(3)
+    lm = build_stub_lm(tiny_config(hidden_size=8, context_token_num=3, tdc_frame_cap=cap, tdc_shard_frames=shard,
+                                   tokenizer_model_max_length=10 ** 9))
+    lm.get_model()._tdc_encoder = MixinEngine(K=3, H=8)
+    vid = make_video(T0)
+    ids = torch.tensor([[11, 12, -200, 13, 14, 15]])
+    with torch.inference_mode():            # as the reference's generate() calls it (cambrian_qwen.py:401)
+        out = lm.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, [vid[None], vid[None]],
+                                                      image_sizes=[(384, 384)], video_indices=[None], prompts=[[1, 2]],
+                                                      audios=[None])
+    return out
+
+
+def _mixin_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out = _mixin_call(True)
+        q.put((rank, out[4].numpy(), out[8]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_mixin_shards_frames_world2_equals_serial():
+    """config.tdc_shard_frames: two gloo processes call the boundary with the same 90-frame video; each encodes its half of
+    the 37 frames config.tdc_frame_cap keeps and both return the serial call's inputs_embeds / final_size, bit for bit"""
+    want = _mixin_call(False)
+    assert want[4].shape[1] > 6 + 37 and len(want[8]) == 37          # the cap of the config key, not the constant 224
+    assert len(_mixin_call(False, cap=224)[8]) == 90
+    # without a process group the key alone changes nothing
+    assert torch.equal(_mixin_call(True)[4], want[4])
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mixin_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r: (torch.from_numpy(a), fs) for r, a, fs in (q.get(timeout=120) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert torch.equal(res[r][0], want[4]), "rank %d differs" % r
+        assert [tuple(x) for x in res[r][1]] == [tuple(x) for x in want[8]]

@@ -259,3 +259,25 @@ def test_weight_prep_layernorm_fold_and_fp8(monkeypatch):
     assert Wt.ln_fusion_enabled(1152, True) and not Wt.ln_fusion_enabled(48, True)
     assert Wt.fp8_enabled(1536, True) and not Wt.fp8_enabled(1152 + 64, True) and not Wt.fp8_enabled(1536, False)
     assert not Wt.ln_fusion_enabled(1152)
+
+
+def test_non_reference_config_keys_are_validated():
+    """config.tdc_* keys: a typo fails with an error that names the key - not a bare KeyError from a table."""
+    from tdc_video_amd import model as M
+    assert M._dtype_key({"tdc_tower_dtype": "bf16"}, "tdc_tower_dtype", allow32=False) == torch.bfloat16
+    assert M._dtype_key({"tdc_tower_res_dtype": "half"}, "tdc_tower_res_dtype") == torch.float16
+    assert M._dtype_key({"tdc_tower_res_dtype": "float32"}, "tdc_tower_res_dtype") is None
+    assert M._dtype_key({}, "tdc_dino_dtype", allow32=False) is None
+    for key, bad, allow32 in (("tdc_tower_dtype", "float8", False), ("tdc_tower_dtype", "float32", False),
+                              ("tdc_tower_res_dtype", "fp64", True), ("tdc_dino_dtype", 16, False)):
+        with pytest.raises(ValueError, match=key):
+            M._dtype_key({key: bad}, key, allow32=allow32)
+    lm = build_stub_lm(tiny_config())
+    assert lm.get_model().tdc_frame_cap() == 224                    # the reference's constant (cambrian_arch.py:907-916,813-822)
+    lm.get_model().config.tdc_frame_cap = 512
+    assert lm.get_model().tdc_frame_cap() == 512
+    for bad in (0, -1, "224", 3.5, True):
+        lm.get_model().config.tdc_frame_cap = bad
+        with pytest.raises(ValueError, match="tdc_frame_cap"):
+            lm.get_model().tdc_frame_cap()
+    assert lm.get_model().tdc_sharded_engine() is None               # no key, no process group
