@@ -139,13 +139,15 @@ def _full_depth_reference(px_s, px_d, T, H, K, mns):
 STATIC_ATOL = {torch.float16: 2.2e-3, torch.bfloat16: 5.5e-3}
 
 
-@pytest.mark.parametrize("tower_dtype,res_dtype,px", [                 # all at the BENCH's own geometry: 384 / 378 px, 27 x 27 -> 24 x 24
-    (torch.float16, None, 384), (torch.bfloat16, None, 384),           # fp32 residual stream (rounds 2-3)
-    (torch.float16, torch.float16, 384),                               # the reference's own arithmetic: fp16 throughout
-    (torch.bfloat16, torch.float16, 384),                              # the bench's type
+@pytest.mark.parametrize("tower_dtype,res_dtype,px,K", [               # all at the BENCH's own geometry: 384 / 378 px, 27 x 27 -> 24 x 24
+    (torch.float16, None, 384, 144), (torch.bfloat16, None, 384, 144),  # fp32 residual stream (rounds 2-3)
+    (torch.float16, torch.float16, 384, 144),                           # the reference's own arithmetic: fp16 throughout
+    (torch.bfloat16, torch.float16, 384, 144),                          # the bench's type
+    (torch.float16, torch.float16, 384, 16),                            # ... and both at K = 16, the released checkpoints'
+    (torch.bfloat16, torch.float16, 384, 16),                           #     context_token_num (only S10 differs: same tower reference)
 ])   # (336 px - no 27 -> 24 resample, round 3's geometry - was measured for all of these in rounds 3-4: DESIGN.md section 2,
      #  profiles/r04_config1_full_depth_test.log; one geometry = one run of the fp32 oracle = a minute of the suite)
-def test_config1_full_depth_end_to_end_vs_oracle(tower_dtype, res_dtype, px):
+def test_config1_full_depth_end_to_end_vs_oracle(tower_dtype, res_dtype, px, K):
     """BASELINE config 1 with NOTHING cut: 8 frames, pixels -> 27-layer SigLIP / 40-layer DINOv2 -> connector -> Q-Former
     (K = 144, max_num_segments = 2 so that the 8 frames are segmented and compressed) -> emitted tokens, against
     oracle.encode_video (cambrian_arch.py:946-966,1653-1667).  px = 336: the configuration's own size (24 x 24 patches, no
@@ -164,10 +166,19 @@ def test_config1_full_depth_end_to_end_vs_oracle(tower_dtype, res_dtype, px):
     import tdc_video_amd  # noqa: F401
     from tdc_video_amd.pipeline import VideoEncoder
     orc = _oracle()
-    H, K, T, mns = 3584, 144, 8, 2
+    H, T, mns = 3584, 8, 2
     px_d = px - 6 if px == 384 else px
-    ref = _full_depth_reference(px, px_d, T, H, K, mns)
+    ref = _full_depth_reference(px, px_d, T, H, 144, mns)
     sd, cfg, vs, vd, ids, r, sims_ref = (ref[k] for k in ("sd", "cfg", "vs", "vd", "ids", "r", "sims_ref"))
+    if K != 144:
+        # only a11-a19 depend on K: the oracle's compressor on the cached full-depth stages (cambrian_arch.py:1507-1709)
+        cfg = dict(cfg, context_token_num=K)
+        if ("vis", K) not in ref:
+            with torch.no_grad():
+                frames, _ = orc.unpad_newline(r["mm_proj"], [(px, px)] * T, sd["image_newline"])
+                ref[("vis", K)] = orc.tdc_compress(torch.stack(frames), r["seg_indices"], torch.tensor(PROMPT), sd, K, 12,
+                                                   cfg["tokenizer_model_max_length"] - 16 - (ids.shape[1] - 1))
+        r = dict(r, visual_tokens=ref[("vis", K)])
     enc = VideoEncoder(sd, cfg, dtype=torch.float16, tower_dtype=tower_dtype, device="cuda:0", siglip_heads=16, dino_heads=24,
                        qformer_heads=12, tower_res_dtype=res_dtype)
     assert len(enc.towers["siglip"].layers) == 27 and len(enc.towers["dino"].layers) == 40
@@ -199,9 +210,9 @@ def test_config1_full_depth_end_to_end_vs_oracle(tower_dtype, res_dtype, px):
     x10 = float((d_stat - 2.0 ** -10 * want[stat_rows].abs()).max())
     x9 = float((d_stat - 2.0 ** -9 * want[stat_rows].abs()).max())
     print("static rows, max over elements of |err| - 2^-10 |ref|: %.3e, of |err| - 2^-9 |ref|: %.3e" % (x10, x9))
-    print("config 1 full depth @%d/%d px, towers %s (residual stream %s) / rest fp16: towers siglip %.3e dino %.3e (of max|ref|); "
+    print("config 1 full depth K=%d @%d/%d px, towers %s (residual stream %s) / rest fp16: towers siglip %.3e dino %.3e (of max|ref|); "
           "similarities max abs err %.3e, ranking margin %.3e; static rows %.3e of max|ref| = %.3e abs (max|ref| %.3f); compressed "
-          "tokens max abs err %.3e" % (px, px_d, tower_dtype, res_dtype or "fp32", es, ed, sim_err, margin, e_stat, a_stat,
+          "tokens max abs err %.3e" % (K, px, px_d, tower_dtype, res_dtype or "fp32", es, ed, sim_err, margin, e_stat, a_stat,
                                        float(want[stat_rows].abs().max()), e_comp))
     assert keep["seg_indices"] == [int(i) for i in r["seg_indices"]] == [2, 5]
     assert keep["selected"] == [int(i) for i in r["selected"]]
@@ -285,18 +296,21 @@ def test_config2_T64_336px_bf16_pipeline_properties(cfg2):
 
 
 # ------------------------------------------------------------------------------------------------------------ config 5
-def test_config5_llama_H3072_connector_compressor_vs_oracle():
-    """S4-S10 at the Llama-3.2-3B width (H = 3072, K = 144) on a 32-frame clip of tower features vs the oracle (fp16)."""
+@pytest.mark.parametrize("K,mns", [(144, 24), (16, 3)])     # K = 16: the released checkpoints' context_token_num (train_video_qwen.sh:51-52,63)
+def test_config5_llama_H3072_connector_compressor_vs_oracle(K, mns):
+    """S4-S10 at the Llama-3.2-3B width (H = 3072) on a 32-frame clip of tower features vs the oracle (fp16); K = 144 with the
+    released max_num_segments = 24 (7 compressed frames), K = 16 with 3 segments (> 20 compressed frames)."""
     import bench
     import tdc_video_amd  # noqa: F401
     from tdc_video_amd.pipeline import VideoEncoder
     from tdc_video_amd import segment as seg
     from tdc_video_amd.weights import pad64
     orc = _oracle()
-    H, K, T = 3072, 144, 32
+    H, T = 3072, 32
     sd = {k: v.float().cpu() for k, v in _sd(H, K, 384).items() if not k.startswith("vision_tower_aux_list")}
     cfg = bench.model_cfg(H, K, T)
     cfg["model_type"] = "llama"
+    cfg["max_num_segments"] = mns
     enc = VideoEncoder(sd, cfg, dtype=torch.float16, device="cuda:0")
     g = torch.Generator().manual_seed(9)
     sig = torch.randn(T, 576, 1152, generator=g).half().float()
@@ -306,7 +320,7 @@ def test_config5_llama_H3072_connector_compressor_vs_oracle():
         q, _ = orc.sva(aux, sd["vision_query"][0], [(384, 384)] * T, sd, 12)
         feat = orc.mm_projector(q, sd)
         frames, _ = orc.unpad_newline(feat, [(384, 384)] * T, sd["image_newline"])
-        segi = orc.select_segments(orc.adjacent_cosine(din), 24)
+        segi = orc.select_segments(orc.adjacent_cosine(din), mns)
         want = orc.tdc_compress(torch.stack(frames), segi, torch.tensor(PROMPT), sd, K, 12, 10 ** 9)
 
     def pad(x, D):
@@ -315,7 +329,7 @@ def test_config5_llama_H3072_connector_compressor_vs_oracle():
         return buf
     keep = {}
     X, _ = enc.connector(pad(sig, 1152), pad(din, 1536), T, [(384, 384)] * T, keep)
-    assert seg.select_segments(enc.sims_tensor(pad(din, 1536), T).tolist(), 24) == [int(i) for i in segi]
+    assert seg.select_segments(enc.sims_tensor(pad(din, 1536), T).tolist(), mns) == [int(i) for i in segi]
     got = enc.compress(X, T, X.shape[0] // T, [int(i) for i in segi], PROMPT, 10 ** 9, keep=keep)
     assert tuple(got.shape) == tuple(want.shape) and got.shape[1] == H
     plan = keep["plan"]
@@ -323,7 +337,9 @@ def test_config5_llama_H3072_connector_compressor_vs_oracle():
     stat_rows = [i for i, e in enumerate(plan["src"]) if e[0] == "f"]
     err_c = float((got[comp_rows].float().cpu() - want[comp_rows]).abs().max())
     err_s = _rel(got[stat_rows], want[stat_rows])
-    print("H=3072: compressed-token max abs err %.3e, static rows rel %.3e" % (err_c, err_s))
+    assert len(plan["comp_frames"]) >= (7 if mns == 24 else 20)
+    print("H=3072 K=%d (%d compressed frames): compressed-token max abs err %.3e, static rows rel %.3e"
+          % (K, len(plan["comp_frames"]), err_c, err_s))
     assert err_c < 1e-3 and err_s < 8e-4, (err_c, err_s)        # measured 1.0e-4 / 5.3e-4
 
 
