@@ -385,6 +385,9 @@ def main():
                          "(8 B per element: rounds 1-3)")
     ap.add_argument("--dino-dtype", default="", choices=["", "bf16", "fp16"], help="operand type of the DINOv2 tower alone "
                     "(config.tdc_dino_dtype; default: the towers' type): fp16 keeps the a5 similarities at the reference's precision")
+    ap.add_argument("--ln-fuse", action="store_true", help="the towers' pre-LayerNorms folded into the neighbouring GEMMs "
+                    "(VideoEncoder(ln_fuse=True)); over the fp16 residual stream this needs --dtype fp16: the consumer GEMMs read the "
+                    "stream itself, no LayerNorm kernel runs inside the layer loop")
     ap.add_argument("--px", type=int, default=384, help="SigLIP input size (DINO uses px-6: 378); 336 -> 336/336")
     ap.add_argument("--fp8-level", type=int, default=1, choices=[1, 2, 3],
                     help="--dtype fp8: 1 = qkv / fc1 (quantised by the LayerNorm kernel), 2 = also out-proj / fc2, "
@@ -471,6 +474,8 @@ def main():
                        "tdc_tower_res_dtype": "float16" if res16 else "float32", "tdc_tower_batch": args.tower_batch,
                        "tdc_fp8_towers": args.fp8_level if args.dtype == "fp8" else 0, "tdc_frame_cap": T,
                        "tdc_two_streams": bool(two_streams)}
+    if args.ln_fuse:
+        product_setting["tdc_ln_fuse"] = True
     if args.dino_dtype:
         product_setting["tdc_dino_dtype"] = {"bf16": "bfloat16", "fp16": "float16"}[args.dino_dtype]
     lm = None
@@ -485,7 +490,7 @@ def main():
     else:
         enc = VideoEncoder(sd, cfg, dtype=dtype, device=dev, siglip_heads=16, dino_heads=24, qformer_heads=12,
                            tower_batch=args.tower_batch, fp8_towers=args.fp8_level if args.dtype == "fp8" else 0,
-                           tower_dtype=tower_dtype, tower_res_dtype=torch.float16 if res16 else None,
+                           tower_dtype=tower_dtype, tower_res_dtype=torch.float16 if res16 else None, ln_fuse=args.ln_fuse,
                            dino_dtype={"bf16": torch.bfloat16, "fp16": torch.float16, "": None}[args.dino_dtype])
         enc.two_streams = bool(two_streams)
     enc.xattn_mode = args.xattn_mode
@@ -585,6 +590,8 @@ def main():
     this_args = dict(frames=T, K=K, hidden=H, gpus=world, tower_batch=args.tower_batch, dtype=args.dtype, px=args.px,
                      audio=bool(args.audio), fp8_level=args.fp8_level if args.dtype == "fp8" else 0,
                      two_streams=int(two_streams), res=args.res)
+    if args.ln_fuse:
+        this_args["ln_fuse"] = True
     gemms = [r for r in recs if r["kind"] == "gemm"]
     shape_of = lambda r: (r["M"], r["N"], r["K"], r["act"], int(r["res"] != 0), r["out_f32"])      # noqa: E731
     if args.dump_gemm_shapes and rank == 0:

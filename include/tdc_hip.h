@@ -53,6 +53,9 @@ typedef struct {
      * Producer (the fp32 residual-stream GEMMs: out_f32, fp32 res, identity c_map / r_map, N % 64 == 0): with x16 != NULL
      * the updated row is also written as 16-bit to x16 [rows, ldx16] and, per row m and 64-column slot s, (mean, M2) of
      * the slot's 64 values to ln_part[(s * M + m) * 2 ..] (slot-major); tdc_ln_finalize turns them into (mean, rstd) per row.
+     * Producer over a 16-bit residual stream (16-bit C and res of one type - in place when C == res -, identity c_map / r_map,
+     * N % 64 == 0, 16-byte aligned rows): ln_part != NULL with x16 == NULL - only the partials are emitted, of the fp32 sums
+     * acc + bias + float(res) that are rounded into C; the consumer then reads the stream itself as its A operand.
      * Consumer (16-bit output, no residual, identity a_map): with ln_stats != NULL, A holds the RAW rows x (x16 of the
      * producer) and W the gamma-folded weight W diag(gamma); the epilogue computes
      *   act(rstd[m] * (acc[m, n] - mean[m] * ln_c1[n]) + bias[n])   == act(LayerNorm(x) W^T + b)
@@ -258,8 +261,10 @@ typedef struct {
                                         fc2 epilogues, 8 B per element), TDC_F16 + 1 / TDC_BF16 + 1 = that 16-bit type (4 B per
                                         element and half the LayerNorm input bytes; fp16 is the reference's own arithmetic: its
                                         HF towers run under torch_dtype=float16, tdc/builder.py:69, residual adds included).
-                                        Sums are formed in fp32 and rounded once: x <- T16(acc + bias + float(x)).  Excludes
-                                        `fused` and `fp8`. */
+                                        Sums are formed in fp32 and rounded once: x <- T16(acc + bias + float(x)).  With
+                                        `fused` (round 6; needs the stream's type == `dtype`): the folded consumers read the
+                                        stream itself, the read-modify-write epilogues emit only the per-slot partials and no
+                                        LayerNorm kernel runs inside the layer loop.  Excludes `fp8`. */
 } tdc_vit_model;
 size_t tdc_vit_workspace_bytes(const tdc_vit_model* m, int B, int H, int W);
 /* px [B,3,H,W] (px_f32 as in tdc_im2col: 0 = `dtype`, 1 = fp32, 2 = the other 16-bit type) -> out [B*out_grid*out_grid, ldo] 16-bit (`out_dtype_p1`); idx0/idx1/frac: bilinear tables

@@ -375,15 +375,23 @@ extern "C" int tdc_vit_fwd(const tdc_vit_model* m, const void* px, int px_f32, i
         // 16-bit residual stream (tdc_vit_model.res_dtype_p1): x lives in the x32 region as rows of type `rt`; the out-projection
         // and fc2 GEMMs read-modify-write it in 16 bits (one rounding of acc + bias + float(x)), the LayerNorms read 16-bit rows
         const int rt = m->res_dtype_p1 - 1;
-        if ((rt != TDC_F16 && rt != TDC_BF16) || m->fused || m->fp8 || (out_dt != TDC_F16 && out_dt != TDC_BF16)) return TDC_E_BADARG;
+        if ((rt != TDC_F16 && rt != TDC_BF16) || m->fp8 || (out_dt != TDC_F16 && out_dt != TDC_BF16)) return TDC_E_BADARG;
+        // fused over the 16-bit stream: the folded consumers (qkv of layers >= 1, every fc1) read the stream ITSELF as their A
+        // operand - operands of the stream's type, whole 64-column slots - and the out-projection / fc2 epilogues emit only the
+        // per-slot (mean, M2) partials: no LayerNorm kernel and no 16-bit row copy inside the layer loop
+        const bool fused16 = m->fused != 0;
+        if (fused16 && (rt != dt || D % 64 != 0)) return TDC_E_BADARG;
         void* x16 = x32;
+        float* part16 = (float*)(ws + w.part);
+        float* stats16 = (float*)(ws + w.stats);
         auto gemm_c16 = [&](const void* A, int lda, const tdc_lin& L, int M, const void* res, int ldres, int res_f32,
-                            tdc_rowmap cmap, tdc_rowmap rmap) {
+                            tdc_rowmap cmap, tdc_rowmap rmap, float* part = nullptr) {
             tdc_gemm_desc d;
             memset(&d, 0, sizeof(d));
             d.A = A; d.lda = lda; d.W = L.w; d.ldw = L.k; d.C = x16; d.ldc = Dp; d.bias = L.b; d.res = res; d.ldres = ldres;
             d.M = M; d.N = L.n; d.K = L.k; d.dtype = dt; d.res_f32 = res_f32; d.c_map = cmap; d.r_map = rmap;
             d.c16_dtype_p1 = rt + 1;
+            d.ln_part = part;
             return tdc_gemm(&d, stream);
         };
         auto ln16 = [&](const float* g, const float* b) {
@@ -400,8 +408,13 @@ extern "C" int tdc_vit_fwd(const tdc_vit_model* m, const void* px, int px_f32, i
         if (m->has_cls) RET_IF(tdc_set_rows16(x16, Dp, B, S, 0, m->cls_row, rt, stream));
         for (int l = 0; l < m->n_layers; ++l) {
             const tdc_vit_layer& L = m->layers_host[l];
-            RET_IF(ln16(L.ln1_g, L.ln1_b));
-            RET_IF(gemm(h16, Dp, L.qkv, qkv, L.qkv.n, rows, dt, TDC_ACT_NONE, 0, nullptr, 0, 0, ident, ident, stream));
+            if (fused16 && L.qkv_c1) {
+                RET_IF(gemm_ln(x16, Dp, L.qkv, qkv, L.qkv.n, rows, dt, TDC_ACT_NONE, 0, nullptr, 0, nullptr, 0, nullptr, stats16,
+                               L.qkv_c1, stream));
+            } else {
+                RET_IF(ln16(L.ln1_g, L.ln1_b));
+                RET_IF(gemm(h16, Dp, L.qkv, qkv, L.qkv.n, rows, dt, TDC_ACT_NONE, 0, nullptr, 0, 0, ident, ident, stream));
+            }
             tdc_attn_desc a;
             memset(&a, 0, sizeof(a));
             const long long bs = (long long)S * L.qkv.n;
@@ -410,6 +423,19 @@ extern "C" int tdc_vit_fwd(const tdc_vit_model* m, const void* px, int px_f32, i
             a.q_rs = a.k_rs = a.v_rs = L.qkv.n; a.o_rs = Dp;
             a.batch = B; a.heads = m->heads; a.head_dim = m->head_dim; a.sq = S; a.sk = S; a.scale = scale; a.dtype = dt;
             RET_IF(tdc_attention(&a, stream));
+            if (fused16) {
+                RET_IF(gemm_c16(attn, Dp, L.out, rows, x16, Dp, 0, ident, ident, part16));
+                RET_IF(tdc_ln_finalize(part16, D / 64, rows, m->eps, stats16, stream));
+                RET_IF(gemm_ln(x16, Dp, L.fc1, mlp, L.fc2.k, rows, dt, m->act, 0, nullptr, 0, nullptr, 0, nullptr, stats16,
+                               L.fc1_c1, stream));
+                if (l + 1 < m->n_layers) {
+                    RET_IF(gemm_c16(mlp, L.fc2.k, L.fc2, rows, x16, Dp, 0, ident, ident, part16));
+                    RET_IF(tdc_ln_finalize(part16, D / 64, rows, m->eps, stats16, stream));
+                } else {
+                    RET_IF(gemm_c16(mlp, L.fc2.k, L.fc2, rows, x16, Dp, 0, ident, ident));
+                }
+                continue;
+            }
             RET_IF(gemm_c16(attn, Dp, L.out, rows, x16, Dp, 0, ident, ident));
             RET_IF(ln16(L.ln2_g, L.ln2_b));
             RET_IF(gemm(h16, Dp, L.fc1, mlp, L.fc2.k, rows, dt, m->act, 0, nullptr, 0, 0, ident, ident, stream));

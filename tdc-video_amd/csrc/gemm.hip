@@ -55,6 +55,13 @@ extern "C" int tdc_gemm(const tdc_gemm_desc* d, void* stream) {
             ((uintptr_t)d->ln_part & 7))
             return TDC_E_BADARG;
     }
+    if (d->ln_part && !d->x16) {   /* the same producer over a 16-bit residual stream: C = TC(acc + bias + float(res)) with
+                                      16-bit C and res, only the partials are emitted (the consumer reads the stream itself) */
+        if (d->out_f32 || !d->res || d->res_f32 || d->act != TDC_ACT_NONE || d->N % 64 != 0 || d->c_map.seg != 0 ||
+            d->r_map.seg != 0 || d->ln_stats || d->in_fp8 || d->out_fp8 || d->c_pad8 || ((uintptr_t)d->ln_part & 7) ||
+            (d->ldc & 7) || (d->ldres & 7) || ((uintptr_t)d->C & 15) || ((uintptr_t)d->res & 15))
+            return TDC_E_BADARG;
+    }
     if (d->ln_stats) {   /* consumer: 16-bit output without residual - or, with fp8 operands, the fp32 residual-stream
                             update (identity row maps); row statistics indexed by the A / C row */
         const bool rmw = d->in_fp8 && d->out_f32 && d->res && d->res_f32 && d->act == TDC_ACT_NONE && !d->x16 &&
@@ -85,7 +92,12 @@ extern "C" int tdc_gemm(const tdc_gemm_desc* d, void* stream) {
             ((uintptr_t)d->out_stats & 7) || !(d->out_w2max > 0.f))
             return TDC_E_BADARG;
     }
-    if (!d->in_fp8 && d->dtype != TDC_F16 && d->dtype != TDC_BF16) return TDC_E_BADARG;
+    if (d->dtype != TDC_F16 && d->dtype != TDC_BF16) return TDC_E_BADARG;      /* with fp8 operands: the type of C / res */
+    if (d->in_fp8 && !d->ln_stats) {   /* e4m3 operands carry their dequantisation scales in ln_stats: without them the product
+                                          would leave unscaled */
+        fprintf(stderr, "[tdc_hip] tdc_gemm: in_fp8 needs ln_stats (the row / weight scales) (M=%d N=%d K=%d)\n", d->M, d->N, d->K);
+        return TDC_E_BADARG;
+    }
     /* every argument check is behind us: a refused launch leaves no profiler record */
 #ifndef TDC_GEMM_DIAG
     TdcProfScope prof(TDC_PROF_GEMM, st, d->M, d->N, d->K, d->act, d->res ? (d->res_f32 ? 1 : 2) : 0, d->out_f32, d->W,

@@ -211,6 +211,20 @@ __device__ __forceinline__ void slot_stats_row16(f32x4 v, float& mean, float& m2
     for (int l = 0; l < 4; ++l) q = q + row16_xch(q, l);
     m2 = q;
 }
+// 16-bit read-modify-write layout (epi_staged_rmw16): the 8 lanes of a row hold groups c = 2 (lane & 7) and c + 1 - the pair
+// c ^ 1 sits in the lane, c ^ 2, c ^ 4, c ^ 8 are the lanes l ^ 1, l ^ 2, l ^ 4 (quad_perm, quad_perm, row_half_mirror)
+__device__ __forceinline__ void slot_stats_row8(f32x4 a, f32x4 b, float& mean, float& m2) {
+    float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3]));
+#pragma unroll
+    for (int l = 0; l < 3; ++l) s = s + row16_xch(s, l);
+    mean = s * 0.015625f;
+    const float d0 = a[0] - mean, d1 = a[1] - mean, d2 = a[2] - mean, d3 = a[3] - mean;
+    const float e0 = b[0] - mean, e1 = b[1] - mean, e2 = b[2] - mean, e3 = b[3] - mean;
+    float q = ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + ((e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3));
+#pragma unroll
+    for (int l = 0; l < 3; ++l) q = q + row16_xch(q, l);
+    m2 = q;
+}
 // MFMA layout: group c = 4 j + g: g across the lanes l ^ 16, l ^ 32, j across the four accumulator tiles of the row
 __device__ __forceinline__ void slot_stats_mfma(const f32x4 (&v)[4], float& mean, float& m2) {
     float s[4];
@@ -326,6 +340,42 @@ __device__ __forceinline__ void epi_tile_emit(const GemmArgs& p, f32x4 (&acc)[MI
     }
 }
 
+// 16-bit residual stream update (C = TC(acc + bias + float(res)), in place when C == res) + per-slot LayerNorm partials of the
+// fp32 sums (ln_part != NULL, x16 == NULL; N % 64 == 0, identity c_map / r_map): the MFMA-layout twin of epi_staged_rmw16<EMIT>
+template <class T, int MI, bool LB, class TC>
+__device__ __forceinline__ void epi_tile_emit16(const GemmArgs& p, f32x4 (&acc)[MI][4], int mbase, int nbase, int fr,
+                                                int g, const EpiLane& el) {
+    typedef typename VecOf<TC>::v4 v4c;
+    if (nbase >= p.N) return;                       // wave-uniform
+    EpiOps<MI, 4, LB, false> ops;
+    ops.load(p, mbase, nbase, fr, g, el);
+    const int slot = nbase >> 6;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = mbase + i * 16 + fr;
+        const int mc = m < p.M ? m : p.M - 1;       // clamped rows compute (the exchanges need every lane), never store
+        f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = nbase + j * 16 + g * 4;
+            const v4c r = *(const v4c*)((const TC*)p.res + (long long)mc * p.ldres + n);
+            v[j] = ops.lin(acc[i][j], i, j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[j][e] += (float)r[e];
+        }
+        float mean, m2;
+        slot_stats_mfma(v, mean, m2);
+        if (m < p.M) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = nbase + j * 16 + g * 4;
+                *(v4c*)((TC*)p.C + (long long)m * p.ldc + n) = cvt4<TC>(v[j]);
+            }
+            if (g == 0) *(float2*)(p.ln_part + 2 * ((long long)slot * p.M + m)) = make_float2(mean, m2);
+        }
+    }
+}
+
 // ---- e4m3 output with analytic per-row scales (tdc_gemm_desc.out_fp8) -----------------------------------------------------
 // Row m of act(A W^T + b) is bounded by B = rstd * ||a8||_2 * max_n ||w8_n||_2 + max|b| (Cauchy-Schwarz on the quantised
 // operands; ops.mean carries the row norm, ops.rstd the row's s_a * s_w), squared for SwiGLU; the row goes out as
@@ -429,6 +479,11 @@ template <class T, int MI, int NJ, bool LB = false>
 __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[MI][NJ], int mbase, int nbase, int fr, int g,
                                          const EpiLane& el = EpiLane()) {
     if (NJ == 4 && p.x16) { epi_tile_emit<T, MI, LB>(p, (f32x4 (&)[MI][4])acc, mbase, nbase, fr, g, el); return; }
+    if (NJ == 4 && p.ln_part) {      // (x16 == NULL) the fold's producer over a 16-bit stream
+        if (p.ctype == TDC_F16) epi_tile_emit16<T, MI, LB, f16>(p, (f32x4 (&)[MI][4])acc, mbase, nbase, fr, g, el);
+        else epi_tile_emit16<T, MI, LB, bf16>(p, (f32x4 (&)[MI][4])acc, mbase, nbase, fr, g, el);
+        return;
+    }
     if (!LB && p.ln_stats) epilogue_f<T, MI, NJ, LB, true>(p, acc, mbase, nbase, fr, g, el);   // lane-held: LNF kernel
     else epilogue_f<T, MI, NJ, LB, false>(p, acc, mbase, nbase, fr, g, el);
 }
@@ -974,7 +1029,10 @@ __device__ __forceinline__ void res_add8(f32x4& a, f32x4& b, typename VecOf<TC>:
     }
 }
 
-template <class TC, int ROWS, bool LB, int RING>
+// EMIT (LayerNorm fusion over a 16-bit residual stream, producer side: ln_part != NULL, x16 == NULL): per row and 64-column slot
+// the (mean, M2) of the fp32 sums that are rounded into the stream - the consumer GEMM reads the stream itself as its A operand,
+// so there is no 16-bit copy to write.  Identity row maps, N % 64 == 0 (host-checked).
+template <class TC, int ROWS, bool LB, int RING, bool EMIT = false>
 __device__ __forceinline__ void epi_staged_rmw16(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase, int nbase,
                                                  int lane, const EpiLane& el) {
     typedef typename VecOf<TC>::v8 v8c;
@@ -997,6 +1055,7 @@ __device__ __forceinline__ void epi_staged_rmw16(const GemmArgs& p, f32x4 (&acc)
         TC* cptr = (TC*)p.C + (long long)(mbase + rrow) * p.ldc + nbase + ck * 8;
         const TC* rptr = (const TC*)p.res + (long long)(mbase + rrow) * p.ldres + nbase + ck * 8;
         const long long cstep = 8ll * p.ldc, rstep = 8ll * p.ldres;
+        float* lptr = EMIT ? p.ln_part + 2 * ((long long)(nbase >> 6) * p.M + mbase + rrow) : nullptr;
         v8c ring[RING];
 #pragma unroll
         for (int u = 0; u < RING; ++u) { ring[u] = *(const v8c*)rptr; rptr += rstep; }
@@ -1025,6 +1084,12 @@ __device__ __forceinline__ void epi_staged_rmw16(const GemmArgs& p, f32x4 (&acc)
                 res_add8<TC>(a, b, rr);
                 __builtin_nontemporal_store(pack8(a, b), (v8c*)cptr);
                 cptr += cstep;
+                if (EMIT) {
+                    float mean, m2;
+                    slot_stats_row8(a, b, mean, m2);
+                    if (ck == 0) *(float2*)lptr = make_float2(mean, m2);
+                    lptr += 16;
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1061,6 +1126,12 @@ __device__ __forceinline__ void epi_staged_rmw16(const GemmArgs& p, f32x4 (&acc)
             res_add8<TC>(a, b, x);
             const int m = mbase + pass * ROWS + r, n = nbase + ck * 8;
             if (m < p.M && n < p.N) __builtin_nontemporal_store(pack8(a, b), (v8c*)((TC*)p.C + p.cm(m) * p.ldc + n));
+            if (EMIT) {
+                float mean, m2;
+                slot_stats_row8(a, b, mean, m2);          // every lane takes part (rows beyond M: clamped duplicates)
+                if (m < p.M && ck == 0 && nbase < p.N)
+                    *(float2*)(p.ln_part + 2 * ((long long)(nbase >> 6) * p.M + m)) = make_float2(mean, m2);
+            }
         }
     }
 }
@@ -1098,7 +1169,11 @@ __device__ __forceinline__ bool epilogue_staged_f(const GemmArgs& p, f32x4 (&acc
     else if (res == 2) {
         if (FOLD || (p.N & 7) || (p.ldres & 7) || ((uintptr_t)p.res & 15)) return false;
         constexpr int RR = SMALL ? 16 : 32;
-        if (p.ctype == TDC_F16) epi_staged_rmw16<f16, RR, SMALL, TDC_RMW16_RING>(p, acc, region, mbase, nbase, lane, el);
+        if (p.ln_part) {         // producer of the LayerNorm fold over a 16-bit stream
+            if (p.ctype == TDC_F16) epi_staged_rmw16<f16, RR, SMALL, TDC_RMW16_RING, true>(p, acc, region, mbase, nbase, lane, el);
+            else epi_staged_rmw16<bf16, RR, SMALL, TDC_RMW16_RING, true>(p, acc, region, mbase, nbase, lane, el);
+        }
+        else if (p.ctype == TDC_F16) epi_staged_rmw16<f16, RR, SMALL, TDC_RMW16_RING>(p, acc, region, mbase, nbase, lane, el);
         else epi_staged_rmw16<bf16, RR, SMALL, TDC_RMW16_RING>(p, acc, region, mbase, nbase, lane, el);
     }
     else epi_staged16<T, 0, 0, R16, SMALL, FOLD>(p, acc, region, mbase, nbase, lane, el);

@@ -389,6 +389,7 @@ class CambrianMetaModel:
                                              siglip_heads=towers[0].heads, dino_heads=towers[1].heads,
                                              qformer_heads=self._qformer_arch["heads"], fp8_towers=fp8,
                                              tower_batch=tb or None, tower_dtype=tower_dtype, dino_dtype=dino_dtype,
+                                             ln_fuse=bool(cfg.get("tdc_ln_fuse", False)),
                                              tower_res_dtype=None if (fp8 and not cfg.get("tdc_tower_res_dtype")) else res)
         return self._tdc_encoder
 

@@ -165,6 +165,12 @@ def gemm(a, w, bias=None, act=L.ACT_NONE, res=None, out=None, out_f32=False, M=N
         assert x16.dtype == a.dtype and x16.shape[0] >= M and x16.shape[1] >= N
         assert ln_part.dtype == torch.float32 and ln_part.is_contiguous() and ln_part.numel() >= M * (N // 64) * 2
         d.x16, d.ldx16, d.ln_part = x16.data_ptr(), x16.stride(0), ln_part.data_ptr()
+    elif ln_part is not None:
+        # the fold's producer over a 16-bit residual stream: only the per-slot partials leave (the consumer reads the stream)
+        assert not out_f32 and res is not None and res.dtype == out.dtype and N % 64 == 0 and c_map is None and r_map is None
+        assert act == L.ACT_NONE and ln_stats is None and not fp8
+        assert ln_part.dtype == torch.float32 and ln_part.is_contiguous() and ln_part.numel() >= M * (N // 64) * 2
+        d.ln_part = ln_part.data_ptr()
     if ln_stats is not None:
         assert ln_c1 is not None and a_map is None and (fp8 or (not out_f32 and res is None))
         assert ln_stats.dtype == torch.float32 and ln_stats.is_contiguous() and ln_stats.numel() >= 2 * M

@@ -72,7 +72,12 @@ class VideoEncoder:
         self.cfg = dict(cfg)
         self.tower_res_dtype = None if tower_res_dtype in (None, torch.float32) else tower_res_dtype
         assert self.tower_res_dtype in (None, torch.float16, torch.bfloat16)
-        assert self.tower_res_dtype is None or not (fp8_towers or ln_fuse)
+        assert self.tower_res_dtype is None or not fp8_towers
+        # the LayerNorm fold over a 16-bit stream: the consumer GEMMs read the stream itself as their A operand, so the
+        # operands of both towers have the stream's type
+        assert not (ln_fuse and self.tower_res_dtype is not None) or \
+            (tower_dtype or dtype) == self.tower_res_dtype == (dino_dtype or tower_dtype or dtype), \
+            "ln_fuse over a 16-bit residual stream needs tower operands of the stream's type"
         self.dtype, self.dev = dtype, torch.device(device)
         self._tower_dtype = tower_dtype = dtype if tower_dtype is None else tower_dtype
         self.tower_batch = tower_batch
@@ -256,11 +261,15 @@ class VideoEncoder:
         # 16-bit row copy (into h16) and per-slot statistics, the next GEMM folds (mean, rstd) into its epilogue
         fused = bool(t.fused)
         fp8 = int(t.get("fp8") or 0)
-        assert s32 or not (fused or fp8), "the LayerNorm fold and the fp8 towers keep the fp32 residual stream"
+        assert s32 or not fp8, "the fp8 towers keep the fp32 residual stream"
+        assert s32 or not fused or rd == dt, "the fold over a 16-bit stream reads the stream as the GEMM operand"
         slots = D // 64
         part = torch.empty(slots, B * S, 2, device=dev, dtype=torch.float32) if fused else None
         stats = torch.empty(B * S, 2, device=dev, dtype=torch.float32) if fused else None
-        emit = dict(x16=h16, ln_part=part) if fused else {}
+        # fp32 stream: the producer also writes the 16-bit row copy the consumer reads; 16-bit stream: the consumer reads the
+        # stream itself - only the partials are emitted and no LayerNorm kernel runs inside the layer loop
+        emit = dict(x16=h16, ln_part=part) if (fused and s32) else dict(ln_part=part) if fused else {}
+        xa = h16 if s32 else x                   # A operand of the folded consumers
         if fp8:     # e4m3 LayerNorm rows (per-row scales in `stats`) for the fp8-operand qkv / fc1 GEMMs
             h8 = torch.empty(B * S, t.layers[0].qkv.w.shape[1], device=dev, dtype=torch.uint8)
             stats = torch.empty(B * S, 2, device=dev, dtype=torch.float32)
@@ -280,7 +289,7 @@ class VideoEncoder:
                 ln(Lr.ln1_g, Lr.ln1_b, y16=h16)
                 ops.gemm(h16, Lr.qkv.w, Lr.qkv.b, out=qkv)
             else:
-                ops.gemm(h16, Lr.qkv.w, Lr.qkv.b, out=qkv, ln_stats=stats, ln_c1=Lr.qkv_c1)
+                ops.gemm(xa, Lr.qkv.w, Lr.qkv.b, out=qkv, ln_stats=stats, ln_c1=Lr.qkv_c1)
             ld = qkv.stride(0)
             ops.attention(qkv[:, 0:D], qkv[:, D:2 * D], qkv[:, 2 * D:3 * D], attn, B, t.heads, t.head_dim, S, S, scale,
                           S * ld, S * ld, S * ld, S * attn.stride(0))
@@ -291,7 +300,7 @@ class VideoEncoder:
                 update(attn, Lr.out, **emit)
             if fused:
                 ops.ln_finalize(part, slots, B * S, t.eps, stats)
-                ops.gemm(h16, Lr.fc1.w, Lr.fc1.b, act=act, out=mlp, ln_stats=stats, ln_c1=Lr.fc1_c1)
+                ops.gemm(xa, Lr.fc1.w, Lr.fc1.b, act=act, out=mlp, ln_stats=stats, ln_c1=Lr.fc1_c1)
             elif fp8:
                 ln(Lr.ln2_g, Lr.ln2_b, y8=h8, y8_stats=stats, y8_wscale=Lr.fc1.wscale)
                 if fp8 >= 3:

@@ -112,6 +112,64 @@ def test_gemm_persistent(ops, dtype, N):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M", [300, 80 * 256 - 19])
+def test_gemm_layernorm_fusion_over_a_16bit_stream(ops, dtype, M):
+    """The fold over a 16-bit residual stream (round 6; tdc_gemm_desc: ln_part without x16): the producer - the 16-bit
+    read-modify-write of the stream, C = T(acc + bias + float(res)) - also emits the per-slot (mean, M2) partials of the fp32 sums
+    it rounds, and the consumer reads the STREAM as its A operand: no 16-bit copy, no LayerNorm kernel.  Checked: the stream the
+    producer writes is bit-equal to the plain read-modify-write; the finalised statistics are the rows' mean / rstd; partials
+    and consumer outputs of a 300-row launch (128 x 128 kernel, MFMA-layout epilogue) are bit-equal to the same rows of the large
+    one (persistent kernel, staged epilogue); the consumer equals LayerNorm(x) W^T + b on the rounded stream."""
+    from tdc_video_amd import lib as L
+    g = torch.Generator(device="cuda").manual_seed(12)
+    D, K, N2, eps = 1152, 256, 1216, 1e-6
+    a = torch.randn(M, K, device="cuda", generator=g).to(dtype)
+    w = (torch.randn(D, K, device="cuda", generator=g) / math.sqrt(K)).to(dtype)
+    b = torch.randn(D, device="cuda", generator=g)
+    x0 = (torch.randn(M, D, device="cuda", generator=g) * 2 + 0.7).to(dtype)     # the stream, non-zero mean
+
+    def producer(a_, x_):
+        x = x_.clone()
+        part = torch.empty(D // 64, x.shape[0], 2, device="cuda", dtype=torch.float32)
+        ops.gemm(a_, w, b, res=x, out=x, ln_part=part)
+        return x, part, ops.ln_finalize(part, D // 64, x.shape[0], eps)
+
+    x, part, stats = producer(a, x0)
+    plain = x0.clone()
+    ops.gemm(a, w, b, res=plain, out=plain)
+    assert torch.equal(x, plain)
+    s32 = a.float() @ w.float().t() + b + x0.float()                          # what the epilogue rounds
+    assert relerr(x, s32) < tol(dtype)
+    mean, rstd = s32.mean(1), (s32.var(1, unbiased=False) + eps).rsqrt()
+    assert (stats[:, 0] - mean).abs().max().item() < 3e-4 * s32.abs().max().item()     # 16-bit operands of the reference product
+    assert ((stats[:, 1] - rstd).abs() / rstd).max().item() < 2e-3
+    gamma = 1.0 + 0.1 * torch.randn(D, device="cuda", generator=g)
+    beta = 0.1 * torch.randn(D, device="cuda", generator=g)
+    w2 = torch.randn(N2, D, device="cuda", generator=g) / math.sqrt(D)
+    b2 = torch.randn(N2, device="cuda", generator=g)
+    wf = (w2 * gamma[None, :]).to(dtype)
+    c1 = wf.float().sum(1).contiguous()
+    c2 = (w2 @ beta + b2).contiguous()
+    lin = F.layer_norm(x.float(), (D,), gamma, beta, eps) @ w2.t() + b2
+    outs = {}
+    for name, act, want in (("none", L.ACT_NONE, lin), ("tanh", L.ACT_GELU_TANH, F.gelu(lin, approximate="tanh")),
+                            ("swiglu", L.ACT_SWIGLU, F.silu(lin[:, 0::2]) * lin[:, 1::2])):
+        outs[name] = ops.gemm(x, wf, c2, act=act, ln_stats=stats, ln_c1=c1)
+        assert relerr(outs[name], want) < 2 * tol(dtype), name
+    if M > 300:
+        for lo in (0, M // 2 + 3, M - 300):
+            xs, parts, statss = producer(a[lo:lo + 300].contiguous(), x0[lo:lo + 300])
+            assert torch.equal(xs, x[lo:lo + 300])
+            assert torch.equal(parts, part[:, lo:lo + 300]) and torch.equal(statss, stats[lo:lo + 300])
+            for name, act in (("none", L.ACT_NONE), ("swiglu", L.ACT_SWIGLU)):
+                sub = ops.gemm(xs, wf, c2, act=act, ln_stats=statss, ln_c1=c1)
+                assert torch.equal(sub, outs[name][lo:lo + 300]), name
+    # refused: the producer form with an fp32 output, an activation or a row map
+    with pytest.raises(Exception):
+        ops.gemm(a, w, b, res=x0.float(), out_f32=True, ln_part=part)
+
+
+@pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("M", [300, 8192, 80 * 256 - 19])
 def test_gemm_layernorm_fusion(ops, dtype, M):
     """LayerNorm fused into the GEMMs around it: the producer (fp32 residual update) also emits the 16-bit row copy and
