@@ -469,7 +469,7 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(0)
     sd = random_state_dict(H, K, dev, gen, siglip_px=px_s)
     two_streams = args.two_streams if args.two_streams >= 0 else int((T + world - 1) // world <= 128)
-    res16 = args.res == "fp16" and args.dtype != "fp8"
+    res16 = args.res == "fp16"
     product_setting = {"dtype": str(dtype).replace("torch.", ""), "tdc_tower_dtype": str(tower_dtype).replace("torch.", ""),
                        "tdc_tower_res_dtype": "float16" if res16 else "float32", "tdc_tower_batch": args.tower_batch,
                        "tdc_fp8_towers": args.fp8_level if args.dtype == "fp8" else 0, "tdc_frame_cap": T,
@@ -698,16 +698,20 @@ def main():
         "metric": "frames/sec encoded+compressed (576->K tokens) at T=%d" % T,
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": ("fp8 (e4m3 operands: %s) + bf16" % ("all four tower GEMMs" if args.fp8_level >= 2 else "qkv / fc1")) if args.dtype == "fp8"
+        "dtype": ("fp8 (e4m3 operands: %s) + bf16, %s tower residual stream" % ("all four tower GEMMs" if args.fp8_level >= 2 else "qkv / fc1", args.res)) if args.dtype == "fp8"
                  else ("bf16 (ViT tower operands, %s residual stream) + fp16 (connector, Q-Former)" % args.res) if args.dtype == "mixed"
                  else "%s (%s tower residual stream)" % (args.dtype, args.res),
         "data": "synthetic",
+        # fp8 is a throughput mode: its outputs are held to a measured contract against the bf16 path (tests/test_hip_configs.py:
+        # test_config5_fp8_contract_vs_bf16), not to the oracle's tolerances
+        "parity": "throughput mode (e4m3 operands: contract vs the bf16 path, DESIGN.md section 2)" if args.dtype == "fp8"
+                  else "parity mode (oracle tolerances, DESIGN.md section 2)",
         "config": {"workload": "one %d-frame video, SigLIP-so400m/14@%d + DINOv2-giant/14@%d towers (729 patches -> 576 "
                                "tokens), SVA 576->144, mm_projector -> H=%d, Q-Former TDC K=%d (N=156, 12 prompt ids), "
                                "random-init weights, frame cap lifted to T, LLM stubbed%s"
                                % (T, px_s, px_d, H, K, ", + %d s of 16 kHz audio through BEATs (50 audio tokens / frame in "
                                   "the Q-Former KV)" % T if args.audio else ""),
-                   "frames": T, "K": K, "hidden": H, "px": px_s, "tower_residual": args.res if args.dtype != "fp8" else "fp32",
+                   "frames": T, "K": K, "hidden": H, "px": px_s, "tower_residual": args.res,
                    # the model-level settings (tdc-video_amd/model.py: CambrianMetaModel.tdc_engine) that build this encoder
                    "product_setting": product_setting,
                    "entry": "mixin: CambrianMetaForCausalLM.prepare_inputs_labels_for_multimodal on a stub LM (value counts its text "

@@ -82,6 +82,17 @@ int gemm_fp8_rmw(const void* A8, int lda, const tdc_lin& L, float* x32, int ld, 
     return tdc_gemm(&d, st);
 }
 
+// ... over a 16-bit residual stream of type `rt` (tdc_vit_model.res_dtype_p1): x <- T16(s_a s_w acc + bias + float(x))
+int gemm_fp8_rmw16(const void* A8, int lda, const tdc_lin& L, void* x16, int ld, int M, int rt, const float* stats,
+                   const float* zeros, void* st) {
+    tdc_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.A = A8; d.lda = lda; d.W = L.w; d.ldw = L.k; d.C = x16; d.ldc = ld; d.bias = L.b; d.res = x16; d.ldres = ld;
+    d.M = M; d.N = L.n; d.K = L.k; d.dtype = rt; d.in_fp8 = 1;
+    d.ln_stats = stats; d.ln_c1 = zeros;
+    return tdc_gemm(&d, st);
+}
+
 int gemm_fp8(const void* A8, int lda, const tdc_lin& L, void* C, int ldc, int M, int dtype, int act, const float* stats,
              const float* zeros, void* st) {
     tdc_gemm_desc d;
@@ -375,7 +386,8 @@ extern "C" int tdc_vit_fwd(const tdc_vit_model* m, const void* px, int px_f32, i
         // 16-bit residual stream (tdc_vit_model.res_dtype_p1): x lives in the x32 region as rows of type `rt`; the out-projection
         // and fc2 GEMMs read-modify-write it in 16 bits (one rounding of acc + bias + float(x)), the LayerNorms read 16-bit rows
         const int rt = m->res_dtype_p1 - 1;
-        if ((rt != TDC_F16 && rt != TDC_BF16) || m->fp8 || (out_dt != TDC_F16 && out_dt != TDC_BF16)) return TDC_E_BADARG;
+        if ((rt != TDC_F16 && rt != TDC_BF16) || (out_dt != TDC_F16 && out_dt != TDC_BF16)) return TDC_E_BADARG;
+        if (m->fp8 && (m->fused || D % 128 != 0)) return TDC_E_BADARG;
         // fused over the 16-bit stream: the folded consumers (qkv of layers >= 1, every fc1) read the stream ITSELF as their A
         // operand - operands of the stream's type, whole 64-column slots - and the out-projection / fc2 epilogues emit only the
         // per-slot (mean, M2) partials: no LayerNorm kernel and no 16-bit row copy inside the layer loop
@@ -408,6 +420,53 @@ extern "C" int tdc_vit_fwd(const tdc_vit_model* m, const void* px, int px_f32, i
         if (m->has_cls) RET_IF(tdc_set_rows16(x16, Dp, B, S, 0, m->cls_row, rt, stream));
         for (int l = 0; l < m->n_layers; ++l) {
             const tdc_vit_layer& L = m->layers_host[l];
+            if (m->fp8) {
+                // e4m3 operands over the 16-bit stream (BASELINE config 5 at the final code): the LayerNorm kernel reads the 16-bit
+                // rows and writes e4m3 rows + scales; out-projection / fc2 read-modify-write the stream in 16 bits - on 16-bit
+                // operands (level 1) or on e4m3 operands with the scales in the fold operands (levels 2, 3)
+                auto ln8 = [&](const float* g_, const float* b_, int ldy8, float wscale) {
+                    tdc_ln_desc d;
+                    memset(&d, 0, sizeof(d));
+                    d.x = x16; d.ldx = Dp; d.x_f32 = 0; d.dtype = rt; d.gamma = g_; d.beta = b_; d.eps = m->eps;
+                    d.rows = rows; d.cols = D; d.y8 = h16; d.ldy8 = ldy8; d.y8_stats = stats16; d.y8_wscale = wscale;
+                    return tdc_layernorm(&d, stream);
+                };
+                RET_IF(ln8(L.ln1_g, L.ln1_b, L.qkv.k, L.qkv_wscale));
+                RET_IF(gemm_fp8(h16, L.qkv.k, L.qkv, qkv, L.qkv.n, rows, dt, TDC_ACT_NONE, stats16, L.zeros, stream));
+                tdc_attn_desc a;
+                memset(&a, 0, sizeof(a));
+                const long long bs = (long long)S * L.qkv.n;
+                a.q = qkv; a.k = qkv + (size_t)D * 2; a.v = qkv + (size_t)2 * D * 2; a.o = attn;
+                a.q_bs = a.k_bs = a.v_bs = bs; a.o_bs = (long long)S * Dp;
+                a.q_rs = a.k_rs = a.v_rs = L.qkv.n; a.o_rs = Dp;
+                a.batch = B; a.heads = m->heads; a.head_dim = m->head_dim; a.sq = S; a.sk = S; a.scale = scale; a.dtype = dt;
+                RET_IF(tdc_attention(&a, stream));
+                if (m->fp8 >= 2) {
+                    RET_IF(tdc_quantize_rows_fp8(attn, Dp, rows, Dp, dt, h16, L.out.k, stats16, L.out_wscale, stream));
+                    RET_IF(gemm_fp8_rmw16(h16, L.out.k, L.out, x16, Dp, rows, rt, stats16, L.zeros, stream));
+                } else {
+                    RET_IF(gemm_c16(attn, Dp, L.out, rows, x16, Dp, 0, ident, ident));
+                }
+                RET_IF(ln8(L.ln2_g, L.ln2_b, L.fc1.k, L.fc1_wscale));
+                const int mlp_ld8 = vit_mlp_ld(m);
+                const int mlp_n = m->act == TDC_ACT_SWIGLU ? L.fc1.n / 2 : L.fc1.n;
+                if (m->fp8 >= 3) {
+                    float* stats2 = stats16 + al256((size_t)rows * 8) / 4;
+                    if (mlp_n != L.fc2.k) return TDC_E_BADARG;
+                    RET_IF(gemm_fp8_out8(h16, L.fc1.k, L.fc1, qkv, L.fc2.k, rows, dt, m->act, stats16, L.zeros, stats2, L.fc1_w2max,
+                                         L.fc1_bmax, L.fc2_wscale, stream));
+                    RET_IF(gemm_fp8_rmw16(qkv, L.fc2.k, L.fc2, x16, Dp, rows, rt, stats2, L.zeros, stream));
+                } else {
+                    RET_IF(gemm_fp8(h16, L.fc1.k, L.fc1, mlp, mlp_ld8, rows, dt, m->act, stats16, L.zeros, stream));
+                    if (m->fp8 == 2) {
+                        RET_IF(tdc_quantize_rows_fp8(mlp, mlp_ld8, rows, mlp_n, dt, qkv, L.fc2.k, stats16, L.fc2_wscale, stream));
+                        RET_IF(gemm_fp8_rmw16(qkv, L.fc2.k, L.fc2, x16, Dp, rows, rt, stats16, L.zeros, stream));
+                    } else {
+                        RET_IF(gemm_c16(mlp, L.fc2.k, L.fc2, rows, x16, Dp, 0, ident, ident));
+                    }
+                }
+                continue;
+            }
             if (fused16 && L.qkv_c1) {
                 RET_IF(gemm_ln(x16, Dp, L.qkv, qkv, L.qkv.n, rows, dt, TDC_ACT_NONE, 0, nullptr, 0, nullptr, 0, nullptr, stats16,
                                L.qkv_c1, stream));

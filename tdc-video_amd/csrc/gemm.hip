@@ -64,8 +64,9 @@ extern "C" int tdc_gemm(const tdc_gemm_desc* d, void* stream) {
     }
     if (d->ln_stats) {   /* consumer: 16-bit output without residual - or, with fp8 operands, the fp32 residual-stream
                             update (identity row maps); row statistics indexed by the A / C row */
-        const bool rmw = d->in_fp8 && d->out_f32 && d->res && d->res_f32 && d->act == TDC_ACT_NONE && !d->x16 &&
-                         d->c_map.seg == 0 && d->r_map.seg == 0;
+        const bool rmw = d->in_fp8 && d->res && d->act == TDC_ACT_NONE && !d->x16 && d->c_map.seg == 0 && d->r_map.seg == 0 &&
+                         ((d->out_f32 && d->res_f32) ||                                       /* fp32 residual stream */
+                          (!d->out_f32 && !d->res_f32 && !d->out_fp8 && d->N % 8 == 0));       /* 16-bit stream of type `dtype` */
         if ((!d->ln_c1 && !d->in_fp8) || (!rmw && (d->out_f32 || d->res)) || d->a_map.seg != 0 || ((uintptr_t)d->ln_stats & 7) ||
             ((uintptr_t)d->ln_c1 & 15))
             return TDC_E_BADARG;

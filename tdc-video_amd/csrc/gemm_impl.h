@@ -456,7 +456,8 @@ __device__ __forceinline__ void epilogue_f(const GemmArgs& p, f32x4 (&acc)[MI][N
     else if (p.act == TDC_ACT_SWIGLU) epi_tile<T, MI, NJ, TDC_ACT_SWIGLU, 0, false, LB, FOLD>(p, acc, mbase, nbase, fr, g, el);
     else if (!p.out_f32 && res == 0) epi_tile<T, MI, NJ, 0, 0, false, LB, FOLD>(p, acc, mbase, nbase, fr, g, el);
     else if (p.out_f32 && res == 1 && FOLD) epi_tile<T, MI, NJ, 0, 1, true, LB, true>(p, acc, mbase, nbase, fr, g, el);
-    else if (FOLD) return;          // (host-checked: the fold exists for 16-bit outputs and for the fp32 residual update)
+    else if (!p.out_f32 && res == 2 && FOLD) epi_tile<T, MI, NJ, 0, 2, false, LB, true>(p, acc, mbase, nbase, fr, g, el);   // fp8 operands: T = the stream's type
+    else if (FOLD) return;          // (host-checked: the fold exists for 16-bit outputs and for the residual-stream updates)
     else if (p.out_f32) {
         if (res == 1) epi_tile<T, MI, NJ, 0, 1, true, LB, false>(p, acc, mbase, nbase, fr, g, el);
         else if (res == 2) epi_tile<T, MI, NJ, 0, 2, true, LB, false>(p, acc, mbase, nbase, fr, g, el);
@@ -1032,13 +1033,14 @@ __device__ __forceinline__ void res_add8(f32x4& a, f32x4& b, typename VecOf<TC>:
 // EMIT (LayerNorm fusion over a 16-bit residual stream, producer side: ln_part != NULL, x16 == NULL): per row and 64-column slot
 // the (mean, M2) of the fp32 sums that are rounded into the stream - the consumer GEMM reads the stream itself as its A operand,
 // so there is no 16-bit copy to write.  Identity row maps, N % 64 == 0 (host-checked).
-template <class TC, int ROWS, bool LB, int RING, bool EMIT = false>
+// FOLD: the row / column operands of EpiOps (fp8 operands: the dequantisation scales of a residual-stream GEMM over a 16-bit stream)
+template <class TC, int ROWS, bool LB, int RING, bool EMIT = false, bool FOLD = false>
 __device__ __forceinline__ void epi_staged_rmw16(const GemmArgs& p, f32x4 (&acc)[8][4], char* region, int mbase, int nbase,
                                                  int lane, const EpiLane& el) {
     typedef typename VecOf<TC>::v8 v8c;
     typedef typename VecOf<TC>::v4 v4c;
     const int fr = lane & 15, g = lane >> 4;
-    EpiOps<8, 4, LB, false> ops;
+    EpiOps<8, 4, LB, FOLD> ops;
     ops.load(p, mbase, nbase, fr, g, el);
     constexpr int NPASS = 128 / ROWS, UP = ROWS / 8, NU = 16;     // unit = 8 rows x 64 columns = one 16-byte store per lane
     const int rrow = lane >> 3, ck = lane & 7;
@@ -1167,8 +1169,13 @@ __device__ __forceinline__ bool epilogue_staged_f(const GemmArgs& p, f32x4 (&acc
     if (p.act == TDC_ACT_GELU_ERF) epi_staged16<T, TDC_ACT_GELU_ERF, 0, R16, SMALL, FOLD>(p, acc, region, mbase, nbase, lane, el);
     else if (p.act == TDC_ACT_GELU_TANH) epi_staged16<T, TDC_ACT_GELU_TANH, 0, R16, SMALL, FOLD>(p, acc, region, mbase, nbase, lane, el);
     else if (res == 2) {
-        if (FOLD || (p.N & 7) || (p.ldres & 7) || ((uintptr_t)p.res & 15)) return false;
+        if ((p.N & 7) || (p.ldres & 7) || ((uintptr_t)p.res & 15)) return false;
         constexpr int RR = SMALL ? 16 : 32;
+        if constexpr (FOLD) {    // fp8 operands of a residual-stream GEMM over a 16-bit stream (scales through the fold operands)
+            if (p.ctype == TDC_F16) epi_staged_rmw16<f16, RR, SMALL, TDC_RMW16_RING, false, true>(p, acc, region, mbase, nbase, lane, el);
+            else epi_staged_rmw16<bf16, RR, SMALL, TDC_RMW16_RING, false, true>(p, acc, region, mbase, nbase, lane, el);
+            return true;
+        }
         if (p.ln_part) {         // producer of the LayerNorm fold over a 16-bit stream
             if (p.ctype == TDC_F16) epi_staged_rmw16<f16, RR, SMALL, TDC_RMW16_RING, true>(p, acc, region, mbase, nbase, lane, el);
             else epi_staged_rmw16<bf16, RR, SMALL, TDC_RMW16_RING, true>(p, acc, region, mbase, nbase, lane, el);
@@ -1718,7 +1725,8 @@ int launch(const tdc_gemm_desc* d, hipStream_t st, bool force128 = false) {
         const int G = persistent_grid();
         const bool fold_ok = !d->ln_stats || d->out_fp8 || (d->out_f32 && d->res && d->res_f32 && d->act == TDC_ACT_NONE) ||
                              (!d->out_f32 && !(d->ldc & 7) && !((uintptr_t)d->C & 15) &&
-                              d->N % (d->act == TDC_ACT_SWIGLU ? 16 : 8) == 0);
+                              d->N % (d->act == TDC_ACT_SWIGLU ? 16 : 8) == 0 &&
+                              (!d->res || (!d->res_f32 && !(d->ldres & 7) && !((uintptr_t)d->res & 15))));
         // rows of A a tile can span: identity 256; mapped m -> (m / seg) * stride + off + (m % seg) * inner, monotone when
         // inner >= 1 and stride >= (seg - 1) * inner + 1: at most 256 / seg + 2 segments are touched
         long long a_span = 256;

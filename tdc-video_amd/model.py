@@ -359,7 +359,7 @@ class CambrianMetaModel:
         `config.tdc_tower_res_dtype = "float16" | "bfloat16" | "float32"`: the towers' residual stream in HBM.  Default:
         "float16" when the towers' operands are fp16 - the reference's own arithmetic, its HF towers run under
         torch_dtype=float16 (tdc/builder.py:69) -, "float32" otherwise (bf16 operands reach 3e38, an fp16 stream ends at 65504:
-        that combination - what bench.py measures - is opt-in); fp8 towers keep the fp32 stream;
+        that combination - what bench.py measures - is opt-in; fp8 towers follow the same rule);
         `config.tdc_tower_batch`: frames per tower batch; default: every frame of the call up to 512, bounded by the free HBM
         (VideoEncoder.auto_tower_batch; the result does not depend on it bit for bit, the reference's own chunk is 64,
         tdc/cambrian_arch.py:698-745);
@@ -390,7 +390,7 @@ class CambrianMetaModel:
                                              qformer_heads=self._qformer_arch["heads"], fp8_towers=fp8,
                                              tower_batch=tb or None, tower_dtype=tower_dtype, dino_dtype=dino_dtype,
                                              ln_fuse=bool(cfg.get("tdc_ln_fuse", False)),
-                                             tower_res_dtype=None if (fp8 and not cfg.get("tdc_tower_res_dtype")) else res)
+                                             tower_res_dtype=res)
         return self._tdc_encoder
 
     def tdc_frame_cap(self):

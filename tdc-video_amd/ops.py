@@ -115,7 +115,9 @@ def gemm(a, w, bias=None, act=L.ACT_NONE, res=None, out=None, out_f32=False, M=N
     if fp8:
         assert w.dtype in FP8_DTYPES and K % 128 == 0 and out_dtype in (torch.float16, torch.bfloat16)
         assert ln_stats is not None, "fp8 operands carry their scales in ln_stats"
-        assert (res is None and not out_f32) or (out_f32 and res is not None and res.dtype == torch.float32)
+        # a residual only as the read-modify-write of the residual stream: fp32, or 16-bit of type `out_dtype`
+        assert (res is None and not out_f32) or (out_f32 and res is not None and res.dtype == torch.float32) or \
+            (not out_f32 and res is not None and res.dtype == out_dtype and out is not None and out.dtype == out_dtype)
     else:
         out_dtype = a.dtype
     assert (fp8 or a.dtype == w.dtype) and K % 64 == 0 and a.shape[1] >= K, (a.shape, w.shape)
@@ -153,7 +155,7 @@ def gemm(a, w, bias=None, act=L.ACT_NONE, res=None, out=None, out_f32=False, M=N
         d.res, d.ldres = res.data_ptr(), res.stride(0)
         d.res_f32 = 1 if res.dtype == torch.float32 else 0
         if not d.res_f32:
-            assert res.dtype == (a.dtype if (out_f32 or fp8) else out.dtype), \
+            assert res.dtype == (a.dtype if out_f32 else out.dtype), \
                 "a 16-bit residual has the type of the 16-bit output (of the operands when the output is fp32)"
     d.M, d.N, d.K = M, N, K
     d.dtype, d.out_f32, d.act = _dtcode(out_dtype), int(out_f32), act
@@ -234,7 +236,9 @@ def layernorm(x, gamma, beta, eps, cols, dtype, y16=None, y32=None, add=None, ad
     d = L.LnDesc()
     d.x_map, d.y_map = _map(x_map), _map(y_map)
     d.x, d.ldx, d.x_f32 = x.data_ptr(), x.stride(0), int(x.dtype == torch.float32)
-    if x.dtype != torch.float32 and (x.dtype != dtype or x16_kernel):
+    if x.dtype != torch.float32 and y8 is not None and y16 is None and y32 is None:
+        dtype = x.dtype        # e4m3 rows out of a 16-bit stream: `dtype` only names the type of x (no 16-bit output is written)
+    elif x.dtype != torch.float32 and (x.dtype != dtype or x16_kernel):
         # 16-bit input of its own type through the 16-bit-to-16-bit kernel (tdc_ln_desc.x_dtype_p1)
         assert y32 is None and y8 is None and add is None and cols % 8 == 0
         d.x_dtype_p1 = _dtcode(x.dtype) + 1

@@ -68,11 +68,11 @@ class VideoEncoder:
         tower_res_dtype: type of the towers' residual stream in HBM - None / torch.float32: fp32 (the out-projection / fc2
         epilogues read-modify-write 8 B per element); torch.float16 (or bfloat16): that 16-bit type - 4 B per element, half
         the LayerNorm input bytes, sums formed in fp32 and rounded once per residual add.  fp16 is the reference's own
-        arithmetic (its HF towers run under torch_dtype=float16, tdc/builder.py:69).  Not with fp8_towers / ln_fuse."""
+        arithmetic (its HF towers run under torch_dtype=float16, tdc/builder.py:69).  Composes with fp8_towers (round 6) and, when the
+        operands have the stream's type, with ln_fuse."""
         self.cfg = dict(cfg)
         self.tower_res_dtype = None if tower_res_dtype in (None, torch.float32) else tower_res_dtype
         assert self.tower_res_dtype in (None, torch.float16, torch.bfloat16)
-        assert self.tower_res_dtype is None or not fp8_towers
         # the LayerNorm fold over a 16-bit stream: the consumer GEMMs read the stream itself as their A operand, so the
         # operands of both towers have the stream's type
         assert not (ln_fuse and self.tower_res_dtype is not None) or \
@@ -249,6 +249,8 @@ class VideoEncoder:
             return ops.layernorm(x, g, b, t.eps, D, dt, x16_kernel=not s32, **kw)
 
         def update(a, lin, **kw):                # x <- x + a lin^T + b, in place (fp32: 8 B per element; 16-bit: one rounding)
+            if not s32 and "out_dtype" in kw:    # e4m3 operands over the 16-bit stream: C / res are of the stream's type
+                kw["out_dtype"] = rd
             return ops.gemm(a, lin.w, lin.b, res=x, out=x, out_f32=s32, **kw)
         h16 = torch.empty(B * S, Dp, device=dev, dtype=dt)
         qkv = torch.empty(B * S, t.layers[0].qkv.w.shape[0], device=dev, dtype=dt) if t.layers else None
@@ -261,7 +263,6 @@ class VideoEncoder:
         # 16-bit row copy (into h16) and per-slot statistics, the next GEMM folds (mean, rstd) into its epilogue
         fused = bool(t.fused)
         fp8 = int(t.get("fp8") or 0)
-        assert s32 or not fp8, "the fp8 towers keep the fp32 residual stream"
         assert s32 or not fused or rd == dt, "the fold over a 16-bit stream reads the stream as the GEMM operand"
         slots = D // 64
         part = torch.empty(slots, B * S, 2, device=dev, dtype=torch.float32) if fused else None

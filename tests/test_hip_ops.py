@@ -254,6 +254,18 @@ def test_gemm_fp8_operands(ops, dtype, M):
     o32 = r32.clone()
     ops.gemm(x8, w8, b, res=o32, out=o32, out_f32=True, ln_stats=stats, ln_c1=c1, out_dtype=dtype)
     assert relerr(o32, lin + r32) < 1e-4
+    # ... and the same update over a 16-bit residual stream (round 6: fp8 towers over the fp16 stream): x <- T(s acc + b + float(x)),
+    # one rounding, in place; rows independent of the kernel that computes them
+    r16 = r32.to(dtype)
+    o16 = r16.clone()
+    ops.gemm(x8, w8, b, res=o16, out=o16, ln_stats=stats, ln_c1=c1, out_dtype=dtype)
+    assert o16.dtype == dtype and relerr(o16, lin + r16.float()) < tol(dtype)
+    if M > 300:
+        for lo in (0, M - 300):
+            sub = r16[lo:lo + 300].clone()
+            ops.gemm(x8[lo:lo + 300].contiguous(), w8, b, res=sub, out=sub, ln_stats=stats[lo:lo + 300].contiguous(), ln_c1=c1,
+                     out_dtype=dtype)
+            assert torch.equal(sub, o16[lo:lo + 300])
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -337,6 +349,14 @@ def test_layernorm_fp8_output(ops, cols):
     assert relerr(deq, ref) < 2 ** -4                    # half an e4m3 ulp at the top of the range
     want = (ref / (st[:, 1] / ws)[:, None]).to(torch.float8_e4m3fn).view(torch.uint8)
     assert (want != y8).float().mean().item() < 1e-3      # same rounding as torch's conversion (ties / 1-ulp LN noise aside)
+    # the same from a 16-bit stream (fp8 towers over the fp16 residual stream): bit-equal to the fp32 input holding the same values
+    for sdt in (torch.float16, torch.bfloat16):
+        xs = x.to(sdt)
+        ya, sa_ = torch.empty_like(y8), torch.empty_like(st)
+        yb, sb_ = torch.empty_like(y8), torch.empty_like(st)
+        ops.layernorm(xs, gm, bt, eps, cols, torch.bfloat16, y8=ya, y8_stats=sa_, y8_wscale=ws)
+        ops.layernorm(xs.float(), gm, bt, eps, cols, torch.bfloat16, y8=yb, y8_stats=sb_, y8_wscale=ws)
+        assert torch.equal(ya, yb) and torch.equal(sa_, sb_), sdt
 
 
 @pytest.mark.parametrize("dtype", DT)
