@@ -315,7 +315,7 @@ def self_launch(n, guard_s=480.0, cmd=None):
             # of the CUs of every XCD (mask bit i = XCD i % 8, CU slot i / 8: every XCD keeps 16 CUs per rank - a mask that
             # empties an XCD would leave the workgroups dispatched to it without a CU).  Set before the child touches the GPU.
             env["ROC_GLOBAL_CU_MASK"] = "0x" + ("f" * 32 if r == 0 else "f" * 32 + "0" * 32)
-            env["TDC_GEMM_PERSIST_GRID"] = "128"
+            env["TDC_BENCH_PERSIST_GRID"] = "128"      # the child passes it to tdc_gemm_set_persistent_grid (the library reads no environment)
         procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else sys.stderr))
     worst = 0
     live = set(range(n))
@@ -459,6 +459,9 @@ def main():
     from tdc_video_amd import ops
     from tdc_video_amd.pipeline import VideoEncoder
     from tdc_video_amd import segment as seg
+    if os.environ.get("TDC_BENCH_PERSIST_GRID"):     # experiment hook of self_launch's CU split (tools/half_chip_gate.sh)
+        from tdc_video_amd import lib as tlib
+        tlib.load().tdc_gemm_set_persistent_grid(int(os.environ["TDC_BENCH_PERSIST_GRID"]))
 
     dtype = torch.float16 if args.dtype in ("fp16", "mixed") else torch.bfloat16          # connector, Q-Former, outputs
     tower_dtype = torch.bfloat16 if args.dtype == "mixed" else dtype                       # the two ViT towers

@@ -91,6 +91,11 @@ int tdc_gemm(const tdc_gemm_desc* d, void* stream);
  * epilogue; 0 (the default) = normal operation.  Prints a warning on stderr when switched on; returns the previous mode.
  * The library reads no environment variable for this. */
 int tdc_gemm_set_debug(int mode);
+/* Workgroups of the persistent GEMM kernel: 0 (default) = one per CU the device reports; a multiple of 8 (>= 8, at most the
+ * device's) for a process confined to part of the chip by a CU mask, which the device properties do not show.  Results never
+ * depend on it.  Prints a note on stderr when set; returns the previous value, -1 when refused.  The library reads no
+ * environment variable for this. */
+int tdc_gemm_set_persistent_grid(int workgroups);
 /* per-row e4m3 quantisation of a 16-bit matrix x [rows, ldx] (cols % 8 == 0, cols <= 4608): y8 [rows, ldy8] = x / s_a[r]
  * with s_a[r] = max|x[r]| / 448 (zero bytes up to the next multiple of 128 columns when ldy8 allows), stats[r] =
  * (0, s_a[r] * wscale) - the operands of an fp8-operand tdc_gemm whose input does not come out of a LayerNorm (the

@@ -37,6 +37,21 @@ extern "C" int tdc_gemm_set_debug(int mode) {
     return old;
 }
 
+int tdc_gemm_persist_grid_override = 0;
+
+extern "C" int tdc_gemm_set_persistent_grid(int workgroups) {
+    const int old = tdc_gemm_persist_grid_override;
+    if (workgroups != 0 && (workgroups < 8 || workgroups % 8 != 0)) {
+        fprintf(stderr, "[tdc_hip] tdc_gemm_set_persistent_grid(%d) refused: 0 (one workgroup per CU) or a multiple of 8\n", workgroups);
+        return -1;
+    }
+    tdc_gemm_persist_grid_override = workgroups;
+    if (workgroups != 0)
+        fprintf(stderr, "[tdc_hip] NOTE: the persistent GEMM kernel is limited to %d workgroups for this process (a CU-masked "
+                        "process on part of the chip); tdc_gemm_set_persistent_grid(0) restores one per CU\n", workgroups);
+    return old;
+}
+
 extern "C" int tdc_gemm(const tdc_gemm_desc* d, void* stream) {
     if (!d || !d->A || !d->W || !d->C || d->M <= 0 || d->N <= 0 || d->K <= 0) return TDC_E_BADARG;
     const int kmul = d->in_fp8 ? 2 * BK : BK;                  /* one 128-byte K tile: 64 16-bit or 128 fp8 values */

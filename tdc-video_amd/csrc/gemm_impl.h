@@ -12,6 +12,7 @@
 // Diagnostic switch of the epilogue (timing experiments only), set through tdc_gemm_set_debug() - never from the
 // environment, so a stale variable cannot silently change what the production library computes.  Defined in gemm.hip.
 extern int tdc_gemm_debug_mode;
+extern int tdc_gemm_persist_grid_override;    // tdc_gemm_set_persistent_grid (gemm.hip): 0 = one workgroup per CU of the device
 
 namespace {
 
@@ -1614,12 +1615,13 @@ inline int persistent_grid() {
             grid[dev] = 0;
         else
             grid[dev] = (prop.multiProcessorCount / 8) * 8;
-        // a process confined to part of the chip (ROC_GLOBAL_CU_MASK / HSA_CU_MASK: the device still reports every CU) says
-        // how many CUs it really owns - one persistent workgroup per CU, a multiple of 8 (the XCD arithmetic of the kernel)
-        const char* g = getenv("TDC_GEMM_PERSIST_GRID");
-        if (g && grid[dev] > 0 && atoi(g) >= 8 && atoi(g) <= grid[dev]) grid[dev] = (atoi(g) / 8) * 8;
         known[dev] = true;
     }
+    // a process confined to part of the chip (ROC_GLOBAL_CU_MASK / HSA_CU_MASK: the device still reports every CU) says how many
+    // CUs it really owns through tdc_gemm_set_persistent_grid - an explicit call that announces itself on stderr, never an
+    // environment variable (a stale one would silently halve the GEMM rate of the whole process)
+    const int o = tdc_gemm_persist_grid_override;
+    if (o >= 8 && o <= grid[dev]) return (o / 8) * 8;
     return grid[dev];
 }
 
@@ -1732,11 +1734,38 @@ int launch(const tdc_gemm_desc* d, hipStream_t st, bool force128 = false) {
         long long a_span = 256;
         bool a_ok = true;
         if (d->a_map.seg > 0) {
-            const long long seg = d->a_map.seg, stride = d->a_map.stride, inner = d->a_map.inner;
-            a_ok = inner >= 1 && stride >= (seg - 1) * inner + 1 && d->a_map.off >= 0;
-            a_span = (256 / seg + 2) * stride + seg * inner;
+            const long long seg = d->a_map.seg, stride = d->a_map.stride, inner = d->a_map.inner, off = d->a_map.off;
+            a_ok = inner >= 1 && stride >= (seg - 1) * inner + 1 && off >= 0;
+            // exact: the map is monotone, so a tile spans am(last row of the tile) - am(first row) + 1 rows; the maximum over the
+            // row tiles (a few thousand integer operations at most, only for the row-mapped launches of the Q-Former)
+            auto am = [&](long long m) { return (m / seg) * stride + off + (m % seg) * inner; };
+            a_span = 1;
+            if (a_ok)
+                for (long long m0 = 0; m0 < a.M; m0 += 256) {
+                    const long long m1 = m0 + 255 < a.M - 1 ? m0 + 255 : a.M - 1;
+                    const long long sp = am(m1) - am(m0) + 1;
+                    if (sp > a_span) a_span = sp;
+                }
         }
-        if (G > 0 && a_ok && a.K >= 128 && fold_ok && a_span * a.lda * 2 < (1ll << 31) && 256ll * a.ldw * 2 < (1ll << 31)) {
+        const bool span_ok = a_span * a.lda * 2 < (1ll << 31) && 256ll * a.ldw * 2 < (1ll << 31);
+        if (!(G > 0 && a_ok && a.K >= 128 && fold_ok && span_ok)) {
+            // a launch big enough for 256 x 256 tiles runs on the 128 x 128 kernel: correct, but well below the persistent
+            // kernel's rate - said once per shape, so that it does not go unnoticed
+            static std::mutex note_mu;
+            static std::unordered_map<unsigned long long, bool> noted;
+            const unsigned long long key = ((unsigned long long)(unsigned)a.M << 40) ^ ((unsigned long long)(unsigned)a.N << 20) ^
+                                           (unsigned long long)(unsigned)a.K;
+            std::lock_guard<std::mutex> lock(note_mu);
+            if (noted.size() < 64 && !noted.count(key)) {
+                noted[key] = true;
+                fprintf(stderr, "[tdc_hip] note: tdc_gemm M=%d N=%d K=%d is large enough for 256 x 256 tiles but runs on the 128 x 128 "
+                                "kernel (%s)\n", a.M, a.N, a.K,
+                        G <= 0 ? "no persistent grid on this device" : !a_ok ? "a_map is not monotone / has a negative offset"
+                        : a.K < 128 ? "K < 128" : !fold_ok ? "no LDS-staged epilogue for this LayerNorm-fold / fp8 form (alignment)"
+                        : "a tile's rows of A or W span 2 GiB or more");
+            }
+        }
+        if (G > 0 && a_ok && a.K >= 128 && fold_ok && span_ok) {
             a.tiles_m = (a.M + 255) / 256;
             a.tiles_n = (a.N + 255) / 256;
             // group height of the tile order (choose_group_m above): fewest operand panels per window of 32 concurrent tiles.

@@ -147,6 +147,7 @@ PROF_TAG_XATTN_BLOCK = 1
 SIGNATURES = {
     "tdc_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
     "tdc_gemm_set_debug": (C.c_int, [C.c_int]),
+    "tdc_gemm_set_persistent_grid": (C.c_int, [C.c_int]),
     "tdc_ln_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "tdc_quantize_rows_fp8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                         C.c_float, C.c_void_p]),

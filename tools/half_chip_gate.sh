@@ -17,13 +17,13 @@ $B --frames 512 > gpurun_out/hc_full.json 2> gpurun_out/hc_full.err && pick gpur
 echo "== 2. whole chip, T=256 (tile-round quantisation of the half video alone)" >> $O
 $B --frames 256 > gpurun_out/hc_full256.json 2> gpurun_out/hc_full256.err && pick gpurun_out/hc_full256.json full256 || exit 1
 echo "== 3. ONE process on half of every XCD (mask $LO, grid 128), T=256, the other half idle" >> $O
-ROC_GLOBAL_CU_MASK=$LO TDC_GEMM_PERSIST_GRID=128 $B --frames 256 > gpurun_out/hc_half_alone.json 2> gpurun_out/hc_half_alone.err && pick gpurun_out/hc_half_alone.json half_alone || exit 1
+ROC_GLOBAL_CU_MASK=$LO TDC_BENCH_PERSIST_GRID=128 $B --frames 256 > gpurun_out/hc_half_alone.json 2> gpurun_out/hc_half_alone.err && pick gpurun_out/hc_half_alone.json half_alone || exit 1
 for rep in a b; do
 echo "== 4$rep. TWO independent processes, disjoint halves, T=256 each, started 0.4 s apart" >> $O
-ROC_GLOBAL_CU_MASK=$LO TDC_GEMM_PERSIST_GRID=128 $B --steps 10 --frames 256 > gpurun_out/hc_pair0$rep.json 2> gpurun_out/hc_pair0$rep.err &
+ROC_GLOBAL_CU_MASK=$LO TDC_BENCH_PERSIST_GRID=128 $B --steps 10 --frames 256 > gpurun_out/hc_pair0$rep.json 2> gpurun_out/hc_pair0$rep.err &
 P0=$!
 sleep 0.4
-ROC_GLOBAL_CU_MASK=$HI TDC_GEMM_PERSIST_GRID=128 $B --steps 10 --frames 256 > gpurun_out/hc_pair1$rep.json 2> gpurun_out/hc_pair1$rep.err &
+ROC_GLOBAL_CU_MASK=$HI TDC_BENCH_PERSIST_GRID=128 $B --steps 10 --frames 256 > gpurun_out/hc_pair1$rep.json 2> gpurun_out/hc_pair1$rep.err &
 P1=$!
 wait $P0 || exit 1
 wait $P1 || exit 1
