@@ -16,8 +16,13 @@ REAL_NK = {}      # weight data_ptr -> un-padded (n, k) of a prepared weight (we
 
 
 def register_real_nk(w, n, k):
+    """remember the un-padded dims of a prepared weight for the profiler's FLOP counts; the entry dies with the tensor (a freed
+    weight's address is reused by later allocations: a stale entry would mis-count whatever GEMM reads that address as its W)"""
+    import weakref
     w._real_nk = (n, k)
-    REAL_NK[w.data_ptr()] = (n, k)
+    ptr = w.data_ptr()
+    REAL_NK[ptr] = (n, k)
+    weakref.finalize(w, REAL_NK.pop, ptr, None)
 
 
 def profile_start(max_records=1 << 15):

@@ -374,8 +374,10 @@ def test_config4_T512_with_512s_of_audio_properties():
     assert torch.equal(a[seps], enc.c.frame_seg[0, :H].to(a.dtype).expand(seps.numel(), H))
 
 
-@pytest.mark.parametrize("dtype,tol,stream16", [(torch.float16, 4.5e-3, False), (torch.bfloat16, 3.7e-2, False),     # measured 2.9e-3 / 2.4e-2 (DINOv2)
-                                                (torch.float16, 6e-3, True)])                                       # measured 4.1e-3
+# (bf16 operands over the fp32 stream - 2.4e-2 measured against a 3.7e-2 bound in rounds 1-5 - left the suite in round 6: the fold is
+#  a non-default alternative and the suite's time budget goes to the configurations a caller can reach by default)
+@pytest.mark.parametrize("dtype,tol,stream16", [(torch.float16, 4.5e-3, False),     # measured 2.9e-3 (DINOv2)
+                                                (torch.float16, 6e-3, True)])       # measured 4.8e-3
 def test_fullsize_ln_fusion_matches_layernorm_kernel(full_sd, dtype, tol, stream16, monkeypatch):
     """VideoEncoder(ln_fuse=True) (pre-LayerNorms folded into the neighbouring GEMMs: 16-bit row copy + per-slot statistics out of the
     residual-stream GEMM, (mean, rstd) folded into the next GEMM's epilogue) against the LayerNorm-kernel path, both
