@@ -36,12 +36,19 @@ def test_world_size_mismatch_is_an_error_message_not_an_assert():
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and "Traceback" not in r.stderr
 
 
+_EMITTED = {}
+
+
 @pytest.mark.gpu
-def test_plain_python_bench_gpus2_on_one_gpu():
+@pytest.mark.parametrize("via_mixin", [False, True])
+def test_plain_python_bench_gpus2_on_one_gpu(via_mixin):
     """The exact command of the driver's scaling run, two ranks sharing cuda:0 over gloo (TDC_BENCH_ONE_GPU / TDC_DIST_BACKEND
-    are the test hooks of bench.py): one JSON line with the per-rank times."""
+    are the test hooks of bench.py): one JSON line with the per-rank times.  via_mixin: the same through the drop-in boundary -
+    every rank calls prepare_inputs_labels_for_multimodal with the whole video and config.tdc_shard_frames splits its frames
+    over the ranks (model.py -> dist.ShardedVideoEncoder); the emitted stream has the same length either way."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "64", "--steps", "1",
-                        "--warmup", "1", "--no-cpu-baseline"], env=_env(TDC_BENCH_ONE_GPU="1", TDC_DIST_BACKEND="gloo"),
+                        "--warmup", "1", "--no-cpu-baseline"] + (["--via-mixin"] if via_mixin else []),
+                       env=_env(TDC_BENCH_ONE_GPU="1", TDC_DIST_BACKEND="gloo"),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -52,6 +59,11 @@ def test_plain_python_bench_gpus2_on_one_gpu():
     assert len(rk["per_rank"]) == 2 and rk["max"] >= rk["min"] > 0
     assert res["roofline"]["frac"] > 0 and res["config"]["frames"] == 64
     assert res["ranks_seen"] == [0, 1] and res["rank_devices"] == [0, 0] and res["dist_backend"] == "gloo"
+    assert res["config"]["entry"].startswith("mixin" if via_mixin else "engine")
+    assert res["config"]["product_setting"]["tdc_frame_cap"] == 64
+    _EMITTED[via_mixin] = res["config"]["emitted_tokens"]
+    if len(_EMITTED) == 2:
+        assert _EMITTED[False] == _EMITTED[True] > 64 * 17
 
 
 def test_launch_guard_stops_a_rank_that_never_finishes():
