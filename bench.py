@@ -385,6 +385,9 @@ def main():
                          "(8 B per element: rounds 1-3)")
     ap.add_argument("--dino-dtype", default="", choices=["", "bf16", "fp16"], help="operand type of the DINOv2 tower alone "
                     "(config.tdc_dino_dtype; default: the towers' type): fp16 keeps the a5 similarities at the reference's precision")
+    ap.add_argument("--selection-refine", type=int, default=-1, choices=[-1, 0, 1], help="a5 at the reference's precision under bf16 "
+                    "DINOv2 operands (VideoEncoder.selection_refine): -1 = automatic (on for bf16 DINOv2 operands), 0 / 1.  The synthetic "
+                    "video's decisive similarity ranks are 0.43 apart, so nothing is re-encoded in the timed region either way")
     ap.add_argument("--ln-fuse", action="store_true", help="the towers' pre-LayerNorms folded into the neighbouring GEMMs "
                     "(VideoEncoder(ln_fuse=True)); over the fp16 residual stream this needs --dtype fp16: the consumer GEMMs read the "
                     "stream itself, no LayerNorm kernel runs inside the layer loop")
@@ -479,6 +482,8 @@ def main():
                        "tdc_two_streams": bool(two_streams)}
     if args.ln_fuse:
         product_setting["tdc_ln_fuse"] = True
+    if args.selection_refine >= 0:
+        product_setting["tdc_selection_refine"] = bool(args.selection_refine)
     if args.dino_dtype:
         product_setting["tdc_dino_dtype"] = {"bf16": "bfloat16", "fp16": "float16"}[args.dino_dtype]
     lm = None
@@ -494,7 +499,8 @@ def main():
         enc = VideoEncoder(sd, cfg, dtype=dtype, device=dev, siglip_heads=16, dino_heads=24, qformer_heads=12,
                            tower_batch=args.tower_batch, fp8_towers=args.fp8_level if args.dtype == "fp8" else 0,
                            tower_dtype=tower_dtype, tower_res_dtype=torch.float16 if res16 else None, ln_fuse=args.ln_fuse,
-                           dino_dtype={"bf16": torch.bfloat16, "fp16": torch.float16, "": None}[args.dino_dtype])
+                           dino_dtype={"bf16": torch.bfloat16, "fp16": torch.float16, "": None}[args.dino_dtype],
+                           selection_refine=None if args.selection_refine < 0 else bool(args.selection_refine))
         enc.two_streams = bool(two_streams)
     enc.xattn_mode = args.xattn_mode
     wav = None
@@ -720,7 +726,10 @@ def main():
                    "entry": "mixin: CambrianMetaForCausalLM.prepare_inputs_labels_for_multimodal on a stub LM (value counts its text "
                             "splice and padding too)" if lm is not None else "engine: VideoEncoder.encode_video",
                    "parallelism": "frames sharded over %d GPU(s)" % world, "two_streams": bool(two_streams),
-                   "emitted_tokens": int(out.shape[0]) - (64 if lm is not None else 0)},
+                   "emitted_tokens": int(out.shape[0]) - (64 if lm is not None else 0),
+                   "selection_refine": {"on": enc.selection_eps is not None, "eps": enc.selection_eps,
+                                        "note": "a5 under bf16 DINOv2 operands: pairs whose similarities decide the selection and lie within "
+                                                "2 eps of each other are re-encoded by an fp16-operand DINOv2 tower; none on this video"}},
         "rank_ms_per_step": None if rank_ms is None else {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
         "ranks_seen": ranks_seen, "rank_devices": rank_devices if world > 1 else [local],
         "dist_backend": (os.environ.get("TDC_DIST_BACKEND", "nccl") + " (RCCL)" * (os.environ.get("TDC_DIST_BACKEND", "nccl") == "nccl")) if world > 1 else None,

@@ -193,6 +193,46 @@ class ShardedVideoEncoder:
             idx = self._maps[key] = torch.from_numpy(pairs).to(device)
         return e.compact_rows(recv, idx, cols)
 
+    def _refine_selection(self, band, sims, mns, eps, px_dino_local_halo, ranges, recompute_halo):
+        """a5 at the reference's precision, sharded (pipeline.encode_video_with does the same serially): the pairs of `band` - the
+        same list on every rank - are re-encoded by the engine's precise DINOv2 tower.  Pair i belongs to the rank that owns frame
+        i; it needs frame i + 1 as well, which for the last local frame is the right neighbour's first: that rank sends the precise
+        feature rows of its first frame (as the boundary exchange of step 1 does for the fast tower), unless the caller handed
+        this rank the halo frame's pixels (recompute_halo).  The refined values are all-gathered in band order; every rank then
+        runs the same host selection."""
+        e, rank, world = self.e, self.rank, self.world
+        lo, hi = ranges[rank]
+        inband = set(band)
+        mine = [i for i in band if lo <= i < hi]
+        frames = {f for i in mine for f in (i, i + 1) if f < hi}
+        send_first = rank > 0 and (lo - 1) in inband and hi > lo and not recompute_halo      # left neighbour's last pair
+        if send_first:
+            frames.add(lo)
+        cross = rank < world - 1 and hi > lo and (hi - 1) in inband                          # my last pair crosses the boundary
+        if cross and recompute_halo:
+            frames.add(hi)                                                                   # its pixels are local (row hi - lo)
+        frames = sorted(frames)
+        feats = {}
+        if frames:
+            idx = torch.tensor([f - lo for f in frames], device=px_dino_local_halo.device)
+            fp = e.precise_dino(px_dino_local_halo[idx])
+            Pp = fp.shape[0] // len(frames)
+            feats = {f: fp[j * Pp:(j + 1) * Pp] for j, f in enumerate(frames)}
+        if not recompute_halo:
+            sends = [(feats[lo].contiguous(), rank - 1)] if send_first else []
+            recvs = []
+            if cross:
+                ref_rows = next(iter(feats.values()))
+                buf = torch.empty_like(ref_rows)
+                feats[hi] = buf
+                recvs = [(buf, rank + 1)]
+            self.comm.exchange(sends, recvs)
+        dev = px_dino_local_halo.device
+        local = e.pair_sims(feats, [(i, i + 1) for i in mine]) if mine else torch.zeros(0, dtype=torch.float32, device=dev)
+        counts = [sum(1 for i in band if l <= i < h) for (l, h) in ranges]
+        refined = self._all_gather_var(local.to(torch.float32), counts).tolist()
+        return seg.select_refined(sims, mns, eps, band, refined)
+
     def encode_video(self, px_siglip_local, px_dino_local_halo, T, image_size, n_text_tokens, prompt_ids, audio=None,
                      sample_indices=None, recompute_halo=False):
         """px_siglip_local: frames [lo,hi) of the T frames that survive a1 (frame_plan); px_dino_local_halo: the same frames for
@@ -266,6 +306,10 @@ class ShardedVideoEncoder:
                 sims = self._all_gather_var(sims_local, counts).tolist()
             assert len(sims) == T - 1
             seg_idx = seg.select_segments(sims, mns)
+            eps = getattr(e, "selection_eps", None)
+            band = seg.selection_band(sims, mns, eps) if eps else []         # host integers: identical on every rank
+            if band:
+                seg_idx = self._refine_selection(band, sims, mns, eps, px_dino_local_halo, ranges, recompute_halo)
         dino = dino_all[: Tl * P]
         # 2. local towers + connector (+ audio rows of the local frames)
         if side is not None:

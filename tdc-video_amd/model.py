@@ -356,6 +356,10 @@ class CambrianMetaModel:
         in `dtype`; `config.tdc_dino_dtype`: the same for the DINOv2 tower alone (it alone drives the a5 segment selection,
         tdc/cambrian_arch.py:832-849: "float16" there keeps the similarities at the reference's own precision under a bf16
         SigLIP tower);
+        `config.tdc_selection_refine` (default: automatic - on when the DINOv2 operands are bf16) / `config.tdc_selection_eps`
+        (default 1e-3): the a5 segment selection at the reference's precision under bf16 DINOv2 operands - the pairs whose
+        similarities decide the selection and lie closer than the operand type's error are re-encoded by an fp16-operand copy of
+        the DINOv2 tower (VideoEncoder.selection_refine; DESIGN.md section 2);
         `config.tdc_tower_res_dtype = "float16" | "bfloat16" | "float32"`: the towers' residual stream in HBM.  Default:
         "float16" when the towers' operands are fp16 - the reference's own arithmetic, its HF towers run under
         torch_dtype=float16 (tdc/builder.py:69) -, "float32" otherwise (bf16 operands reach 3e38, an fp16 stream ends at 65504:
@@ -381,6 +385,13 @@ class CambrianMetaModel:
             else:
                 res = torch.float16 if (tower_dtype or dtype) == torch.float16 and (dino_dtype or tower_dtype or dtype) == \
                     torch.float16 else None
+            sel_refine = cfg.get("tdc_selection_refine")            # None = automatic (on under bf16 DINOv2 operands)
+            if sel_refine is not None and not isinstance(sel_refine, bool):
+                raise ValueError("config.tdc_selection_refine must be True / False (or absent for the automatic choice), got %r"
+                                 % (sel_refine,))
+            sel_eps = cfg.get("tdc_selection_eps", 1e-3)
+            if isinstance(sel_eps, bool) or not isinstance(sel_eps, (int, float)) or not (0 < sel_eps < 1):
+                raise ValueError("config.tdc_selection_eps must be a similarity error bound in (0, 1), got %r" % (sel_eps,))
             tb = cfg.get("tdc_tower_batch")
             if tb is not None and (isinstance(tb, bool) or not isinstance(tb, int) or tb < 0):
                 raise ValueError("config.tdc_tower_batch must be a positive frame count (or 0 / absent for the automatic "
@@ -390,6 +401,7 @@ class CambrianMetaModel:
                                              qformer_heads=self._qformer_arch["heads"], fp8_towers=fp8,
                                              tower_batch=tb or None, tower_dtype=tower_dtype, dino_dtype=dino_dtype,
                                              ln_fuse=bool(cfg.get("tdc_ln_fuse", False)),
+                                             selection_refine=sel_refine, selection_eps=sel_eps,
                                              tower_res_dtype=res)
         return self._tdc_encoder
 

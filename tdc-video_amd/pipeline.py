@@ -49,7 +49,7 @@ class _LRU(dict):
 class VideoEncoder:
     def __init__(self, sd, cfg, dtype=torch.float16, device="cuda", siglip_heads=16, dino_heads=24,
                  qformer_heads=12, tower_batch=None, fp8_towers=False, tower_dtype=None, ln_fuse=False,
-                 tower_res_dtype=None, dino_dtype=None):
+                 tower_res_dtype=None, dino_dtype=None, selection_refine=None, selection_eps=1e-3):
         """sd: reference-named state dict without the leading 'model.'; cfg: dict of reference config keys.
         dtype: 16-bit type of the connector, the Q-Former and every tensor handed to the caller; tower_dtype (default:
         dtype): 16-bit type of the two ViT towers - their last kernel (the token-grid resample) writes `dtype` rows.  bf16
@@ -58,6 +58,12 @@ class VideoEncoder:
         dino_dtype (default: tower_dtype): operand type of the DINOv2 tower alone.  Its features alone drive the a5 segment
         selection (tdc/cambrian_arch.py:832-849): fp16 there keeps the adjacent-frame similarities at the reference's own
         precision (3.4e-5 instead of 4.2e-4 with bf16 operands) while SigLIP stays in tower_dtype.
+        selection_refine (None = automatic: on when the DINOv2 operands are bf16 and not e4m3) / selection_eps: the a5 segment
+        selection at the reference's precision under bf16 DINOv2 operands.  bf16 similarities are within selection_eps of the fp16
+        tower's (measured 3.7e-4 ... 4.2e-4; default bound 1e-3); when the ranks that decide the selection are closer than
+        2 selection_eps, the pairs inside that band - and only they - are re-encoded by a second, fp16-operand copy of the DINOv2
+        tower (+2.2 GB of weights) and re-ranked (segment.selection_band / select_refined): exactly what ranking the fp16 tower's
+        similarities selects.  A video whose decisive ranks are further apart (the bench's: 0.43) pays nothing.
         fp8_towers (BASELINE config 5): the towers' LayerNorms emit e4m3 rows with per-row scales and the qkv / fc1 GEMMs
         run on fp8 operands (v_mfma_f32_16x16x128_f8f6f4); everything else stays in `tower_dtype`.
         ln_fuse: the towers' pre-LayerNorms folded into the neighbouring GEMMs (weights.ln_fusion_enabled; off by default).
@@ -92,6 +98,18 @@ class VideoEncoder:
                                                ln_fuse=ln_fuse)
         for t in self.towers.values():
             t["dtype"] = dino_dtype or tower_dtype if t.kind == "dino" else tower_dtype
+        # a5 at the reference's precision under bf16 DINOv2 operands: a second, fp16-operand DINOv2 tower for the pairs whose
+        # similarities decide the selection (encode_video_with / dist.ShardedVideoEncoder: selection_band -> refine_pairs)
+        if selection_refine is None:
+            selection_refine = bool(d_sd) and (dino_dtype or tower_dtype) == torch.bfloat16 and not fp8_towers
+        self.selection_eps = None
+        if selection_refine and d_sd and (dino_dtype or tower_dtype) != torch.float16:
+            tp = Wt.prep_dino(d_sd, dino_heads, torch.float16, self.dev)
+            tp["dtype"] = torch.float16
+            # its residual stream: fp16 (the reference's arithmetic) when the engine's is 16-bit, else the engine's fp32
+            tp["res_dtype"] = torch.float16 if self.tower_res_dtype is not None else None
+            self.towers["dino_precise"] = tp
+            self.selection_eps = float(selection_eps)
         self.c = Wt.prep_connector(sd, cfg, dtype, self.dev)
         tok = cfg.get("mm_vision_tower_aux_token_len_list", [576, 576])
         self.out_grid = [int(round(t ** 0.5)) for t in tok]
@@ -126,7 +144,7 @@ class VideoEncoder:
     def tower(self, name, px):
         """px [B,3,H,W] (fp32, fp16 or bf16) -> features [B*g*g, pad64(D)] 16-bit `dtype` (g = 24)."""
         t = self.towers[name]
-        out_grid = self.out_grid[0 if name == "siglip" else 1]
+        out_grid = self.out_grid[0 if name == "siglip" else 1]      # "dino" / "dino_precise": the second entry
         outs = []
         tb = int(self.tower_batch) if self.tower_batch else self.auto_tower_batch(t, px)
         for s in range(0, px.shape[0], tb):
@@ -183,7 +201,7 @@ class VideoEncoder:
                                    Lr.out.wscale or 0.0, Lr.fc2.wscale or 0.0, Lr.fc1.w2max, Lr.fc1.bmax)
         m = L.VitModel()
         m.dtype, m.out_dtype_p1 = ops._dtcode(self._tdt(t)), ops._dtcode(self.dtype) + 1
-        rd = getattr(self, "tower_res_dtype", None)
+        rd = t["res_dtype"] if "res_dtype" in t else getattr(self, "tower_res_dtype", None)
         m.res_dtype_p1 = 0 if rd is None else ops._dtcode(rd) + 1
         m.dim, m.heads, m.head_dim, m.n_layers, m.patch, m.has_cls = t.dim, t.heads, t.head_dim, len(t.layers), t.patch, \
             t.has_cls
@@ -230,7 +248,7 @@ class VideoEncoder:
         if getattr(self, "native_towers", True) and len(t.layers) > 0:
             return self._tower_batch_native(t, px, out_grid)
         dt, dev = self._tdt(t), self.dev
-        rd = getattr(self, "tower_res_dtype", None)
+        rd = t["res_dtype"] if "res_dtype" in t else getattr(self, "tower_res_dtype", None)
         s32 = rd is None                         # fp32 residual stream
         B = px.shape[0]
         D, Dp = t.dim, pad64(t.dim)
@@ -367,6 +385,16 @@ class VideoEncoder:
     def frame_sims(self, dino_feat, T):
         """same as a python list (one D2H copy: the segmentation is host logic)."""
         return self.sims_tensor(dino_feat, T).tolist()
+
+    def precise_dino(self, px):
+        """px [n, 3, H, W] -> DINOv2 features [n * P, pad64(D)] from the fp16-operand copy of the tower (selection refinement)"""
+        return self.tower("dino_precise", px)
+
+    def pair_sims(self, feats, pairs):
+        """feats: {frame: [P, Dp] feature rows}; pairs: [(a, b)] -> device fp32 tensor of cos-sim(feats[a], feats[b]) (the a5
+        kernel on consecutive (a, b) blocks, every second value)"""
+        rows = torch.cat([feats[f] for ab in pairs for f in ab], 0)
+        return self.sims_tensor(rows, 2 * len(pairs))[0::2].contiguous()
 
     # ------------------------------------------------------------------------------------------------ a6-a10
     def aux_project(self, feat, i):
@@ -951,7 +979,22 @@ def encode_video_with(e, px_siglip, px_dino, image_size, budget_text_len, n_text
             # so the device keeps working while the host ranks them (a3) - and read them on a side stream (fetch), so the
             # host does not wait for the tower either
             sig = e.tower("siglip", px_siglip)
-        seg_idx = seg.select_segments(e.fetch(sims_dev, ev) if ev is not None else sims_dev.tolist(), mns)
+        sims = e.fetch(sims_dev, ev) if ev is not None else sims_dev.tolist()
+        seg_idx = seg.select_segments(sims, mns)
+        # a5 at the reference's precision (engine.selection_eps: bf16 DINOv2 operands with the fp16 copy of the tower at hand): when
+        # the ranks that decide the selection are closer than the operand type's error, the pairs in that band are re-encoded
+        eps = getattr(e, "selection_eps", None)
+        band = seg.selection_band(sims, mns, eps) if eps else []
+        if band:
+            frames = seg.band_frames(band)
+            pxd = px_dino if len(sel2) == px_dino.shape[0] else px_dino[torch.tensor(sel2, device=px_dino.device)]
+            fp = e.precise_dino(pxd[torch.tensor(frames, device=pxd.device)])
+            Pp = fp.shape[0] // len(frames)
+            feats = {f: fp[j * Pp:(j + 1) * Pp] for j, f in enumerate(frames)}
+            refined = e.pair_sims(feats, [(i, i + 1) for i in band]).tolist()
+            seg_idx = seg.select_refined(sims, mns, eps, band, refined)
+        if info is not None:
+            info["refined_pairs"] = list(band)
     if side is not None:
         torch.cuda.current_stream().wait_stream(side)
         sig = sig_early

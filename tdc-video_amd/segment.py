@@ -31,6 +31,49 @@ def select_segments(sims, max_num_segments=24):
     return sorted(order)
 
 
+def selection_band(sims, max_num_segments, eps):
+    """Which adjacent-frame similarities must be known more precisely before the a5 selection (tdc/cambrian_arch.py:849) can be
+    trusted, when `sims` are within `eps` of the values a more precise tower would give (bf16 DINOv2 operands against the
+    reference's fp16: measured 3.7e-4 ... 4.2e-4).
+    With v_n / v_n1 the n-th and (n+1)-th smallest value (n = max_num_segments): if v_n1 - v_n > 2 eps no error of that size can
+    swap a selected pair with an unselected one - the selection is already the precise one, and [] is returned.  Otherwise every
+    index with v_n - 2 eps <= sims[i] <= v_n1 + 2 eps is returned (ascending): pairs below that band are selected whatever their
+    precise values are, pairs above it never are (at least n + 1 values are smaller by more than the error), so only the band has
+    to be re-ranked (`select_refined`)."""
+    n = len(sims)
+    if n <= max_num_segments or eps is None or eps <= 0:
+        return []
+    order = sorted(range(n), key=lambda i: (sims[i], i))
+    v_n, v_n1 = sims[order[max_num_segments - 1]], sims[order[max_num_segments]]
+    if v_n1 - v_n > 2.0 * eps:
+        return []
+    lo, hi = v_n - 2.0 * eps, v_n1 + 2.0 * eps
+    return [i for i in range(n) if lo <= sims[i] <= hi]
+
+
+def select_refined(sims, max_num_segments, eps, band, refined):
+    """The selection after the band's similarities were recomputed precisely (`refined[j]` belongs to pair `band[j]`): every pair
+    below the band, plus the lowest of the band by (refined value, index) - the stable ranking of select_segments - up to
+    max_num_segments.  With refined == the precise tower's values this is exactly what ranking ALL of that tower's similarities
+    selects, as long as |sims - precise| <= eps."""
+    if not band:
+        return select_segments(sims, max_num_segments)
+    assert len(band) == len(refined)
+    inband = set(band)
+    order = sorted(range(len(sims)), key=lambda i: (sims[i], i))
+    v_n = sims[order[max_num_segments - 1]]
+    low = [i for i in range(len(sims)) if sims[i] < v_n - 2.0 * eps and i not in inband]
+    need = max_num_segments - len(low)
+    assert 0 <= need <= len(band), (need, len(band), len(low))
+    ranked = sorted(range(len(band)), key=lambda j: (refined[j], band[j]))[:need]
+    return sorted(low + [band[j] for j in ranked])
+
+
+def band_frames(band):
+    """frames whose precise features the band's pairs need: pair i = frames (i, i + 1); ascending, no duplicates"""
+    return sorted({f for i in band for f in (i, i + 1)})
+
+
 def chunk_table(T, seg_indices):
     """tdc/cambrian_arch.py:1541-1545, :1603-1608: segments split at seg+1, then <=8-frame chunks -> [(start, end)]."""
     pts = [0] + [int(s) + 1 for s in seg_indices] + [T]

@@ -84,6 +84,27 @@ class FakeEngine:
         return torch.stack([tabs[int(k)][int(r)] for k, r in pairs]) if len(pairs) else torch.zeros(0, self.H)
 
 
+class NoisyEngine(FakeEngine):
+    """FakeEngine whose ordinary DINO tower is a slightly perturbed copy of a `precise` one (as bf16 operands are of fp16 ones) and
+    which offers the precise tower for the a5 selection refinement (segment.selection_band / select_refined): the per-frame
+    perturbation moves the adjacent-frame similarities by less than selection_eps."""
+    selection_eps = 2e-3
+
+    def precise_dino(self, px):
+        return FakeEngine.tower(self, "dino", px)
+
+    def tower(self, name, px):
+        f = FakeEngine.tower(self, name, px)
+        if name == "dino":
+            f = f * (1.0 + 2e-4 * torch.sin(977.0 * f))
+        return f
+
+    def pair_sims(self, feats, pairs):
+        a = torch.stack([feats[i].reshape(-1) for i, _ in pairs])
+        b = torch.stack([feats[j].reshape(-1) for _, j in pairs])
+        return torch.nn.functional.cosine_similarity(a, b, dim=1)
+
+
 def make_video(T):
     g = torch.Generator().manual_seed(5)
     base = torch.rand(3, 2, 2, generator=g)
@@ -108,12 +129,17 @@ CASES = {
     "cap90": (90, 10 ** 9, 5, {}, False, 37),                             # a1 cap: 90 frames -> 37 kept
     "cap90_audio": (90, 10 ** 9, 5, {"audio_input": True}, True, 37),     # ... dropped seconds folded into kept frames
     "budget120": (120, 20 + 4 + 16 + 3 * 30, 5, {}, False, 10 ** 6),      # a1 budget (get_max_num_frames) + a19 clip
+    # a5 refinement: near-tied similarities under a perturbed tower, the band's pairs re-encoded by the precise one - incl. pairs
+    # that cross a rank boundary (precise boundary features exchanged) and ranks that own no band pair
+    "refine61": (61, 10 ** 9, 5, {"refine": True}, False, 10 ** 6),
+    "refine90_few": (90, 10 ** 9, 5, {"refine": True, "max_num_segments": 17}, False, 10 ** 6),
 }
 
 
 def _case(name):
     T0, max_len, N, over, with_audio, cap = CASES[name]
-    eng = FakeEngine(max_len=max_len, N=N, **over)
+    over = dict(over)
+    eng = (NoisyEngine if over.pop("refine", False) else FakeEngine)(max_len=max_len, N=N, **over)
     vid = make_video(T0)
     audio = None
     if with_audio:
@@ -156,7 +182,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("name", ["plain61", "passthrough20", "clip61", "learned61", "cap90_audio", "budget120"])
+@pytest.mark.parametrize("name", ["plain61", "passthrough20", "clip61", "learned61", "cap90_audio", "budget120", "refine61"])
 def test_sharded_equals_serial_world2(name):
     """two processes over gloo: the product transport (TorchComm) end to end"""
     world = 2
@@ -216,13 +242,56 @@ def test_sharded_equals_serial_any_world(name, world):
         assert got.shape == want.shape and torch.equal(got, want), "rank %d of %d differs" % (r, world)
 
 
-@pytest.mark.parametrize("name", ["plain61", "cap90_audio"])
+@pytest.mark.parametrize("name", ["plain61", "cap90_audio", "refine61"])
 def test_boundary_frame_reencoded_instead_of_exchanged(name):
     """frame_plan(halo=True): the caller hands every rank the next rank's first frame and it is re-encoded locally (round 1's
     form) - same stream as the exchange of its DINOv2 features"""
     want = _serial(name)
     for r, got in enumerate(_threads(name, 4, halo=True)):
         assert got.shape == want.shape and torch.equal(got, want), "rank %d differs" % r
+
+
+def test_selection_refinement_gives_the_precise_towers_selection():
+    """the refine cases: the perturbed tower's similarities leave a non-empty band, and the refined selection is what ranking the
+    PRECISE tower's similarities selects - through the serial orchestration (info["seg_indices"])"""
+    for name in ("refine61", "refine90_few"):
+        eng, vid, audio, cap = _case(name)
+        mns = eng.cfg["max_num_segments"]
+        T = vid.shape[0]
+        noisy = eng.sims_tensor(eng.tower("dino", vid), T).tolist()
+        precise = eng.sims_tensor(eng.precise_dino(vid), T).tolist()
+        assert max(abs(a - b) for a, b in zip(noisy, precise)) < eng.selection_eps
+        band = seg.selection_band(noisy, mns, eng.selection_eps)
+        assert len(band) >= 2 and len(band) < T - 1
+        info = {}
+        pipeline.encode_video_with(eng, vid, vid, (384, 384), budget_text_len=4, n_text_tokens=4, prompt_ids=[1, 2], frame_cap=cap,
+                                   info=info)
+        assert info["refined_pairs"] == band
+        assert info["seg_indices"] == seg.select_segments(precise, mns)
+    # a band that covers a rank boundary exists in the sharded runs of these cases (world 4 / 8 over 61 frames)
+    eng, vid, _, _ = _case("refine61")
+    band = set(seg.selection_band(eng.sims_tensor(eng.tower("dino", vid), 61).tolist(), 24, eng.selection_eps))
+    assert any((h - 1) in band for (l, h) in seg.shard_ranges(61, 4)[:-1])
+
+
+def test_selection_band_property():
+    """selection_band / select_refined: for similarities within eps of the precise ones, re-ranking only the band by the precise
+    values selects exactly what ranking all precise values selects (ties and dense clusters included); a gap wider than 2 eps at
+    the decisive rank needs nothing"""
+    import random
+    rng = random.Random(1)
+    for trial in range(1500):
+        n, mns = rng.choice([30, 60, 511]), rng.choice([2, 5, 24])
+        eps, spread = rng.choice([1e-3, 3e-3, 1e-2]), rng.choice([0.02, 0.25, 1.0])
+        ref = [rng.random() * spread for _ in range(n)]
+        if trial % 7 == 0:
+            for k in range(0, n - 1, 3):
+                ref[k + 1] = ref[k]
+        noisy = [v + (rng.random() * 2 - 1) * eps * 0.999 for v in ref]
+        band = seg.selection_band(noisy, mns, eps)
+        assert seg.select_refined(noisy, mns, eps, band, [ref[i] for i in band]) == seg.select_segments(ref, mns)
+    assert seg.selection_band([0.1, 0.2, 0.5, 0.9], 2, 0.01) == [] and seg.selection_band([0.1, 0.2], 2, 0.01) == []
+    assert seg.selection_band([0.1, 0.2, 0.21, 0.9], 2, 0.01) == [1, 2] and seg.band_frames([1, 2, 7]) == [1, 2, 3, 7, 8]
 
 
 def test_cases_exercise_what_they_claim():

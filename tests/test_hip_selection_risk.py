@@ -45,10 +45,15 @@ def _inversions(ref, got):
     return float(dr[bad].max()) if bad.any() else 0.0, int(bad.sum())
 
 
-def test_selection_risk_of_the_dino_operand_type():
+@pytest.fixture(scope="module")
+def world():
+    return build_world()
+
+
+def build_world():
+    """the bench-type encoder at full size (both towers: the second test runs the whole path) + the slow-drift video"""
     import bench
     import tdc_video_amd  # noqa: F401
-    from tdc_video_amd import segment as seg
     from tdc_video_amd import weights as Wt
     from tdc_video_amd.pipeline import VideoEncoder
     dev = torch.device("cuda", 0)
@@ -56,19 +61,22 @@ def test_selection_risk_of_the_dino_operand_type():
     H, K = 3584, 144
     sd = bench.random_state_dict(H, K, dev, gen)
     d_sd = {k[len("vision_tower_aux_list.1.vision_tower."):]: v for k, v in sd.items() if k.startswith("vision_tower_aux_list.1.")}
-    sd = {k: v for k, v in sd.items() if not k.startswith("vision_tower_aux_list.0.")}       # DINOv2 + connector: a5 needs no SigLIP
-    enc = VideoEncoder(sd, bench.model_cfg(H, K, T), dtype=torch.float16, device=dev, tower_batch=512)
+    enc = VideoEncoder(sd, bench.model_cfg(H, K, T), dtype=torch.float16, device=dev, tower_batch=512, tower_dtype=torch.bfloat16,
+                       tower_res_dtype=torch.float16)
     del sd
     torch.cuda.empty_cache()
 
     def sims_of(video, operand, stream):
+        """similarities of `video` through a DINOv2 tower of the given operand / stream types (the engine's own tower restored)"""
+        keep = enc.towers["dino"], enc.tower_res_dtype
         t = Wt.prep_dino(d_sd, 24, operand, dev)
         t["dtype"] = operand
         enc.towers["dino"] = t
         enc.tower_res_dtype = stream
-        s = enc.sims_tensor(enc.tower("dino", video), video.shape[0]).cpu().tolist()
-        del enc.towers["dino"]
-        return s
+        try:
+            return enc.sims_tensor(enc.tower("dino", video), video.shape[0]).cpu().tolist()
+        finally:
+            enc.towers["dino"], enc.tower_res_dtype = keep
 
     g = torch.Generator(device=dev).manual_seed(77)
     A = torch.rand(3, 378, 378, device=dev, generator=g) * 2 - 1
@@ -83,8 +91,12 @@ def test_selection_risk_of_the_dino_operand_type():
     steps = np.interp(targets, q_mono, ladder.cpu().numpy())
     rng = np.random.RandomState(5)
     steps = torch.tensor(steps[rng.permutation(T - 1)], device=dev, dtype=torch.float32)
-    video = _video(A, B, steps)
+    return enc, sims_of, _video(A, B, steps)
 
+
+def test_selection_risk_of_the_dino_operand_type(world):
+    from tdc_video_amd import segment as seg
+    enc, sims_of, video = world
     ref = sims_of(video, torch.float16, None)
     srt = np.sort(np.asarray(ref))
     gaps = np.diff(srt)
@@ -115,3 +127,55 @@ def test_selection_risk_of_the_dino_operand_type():
     assert e16 < 4.5e-5 and g16 < 1.0e-4, (e16, g16)
     assert eb < 5.5e-4 and gb < 4.6e-4, (eb, gb)
     assert g16 < gb                                            # what config.tdc_dino_dtype = "float16" buys
+
+
+def test_refinement_gives_the_bench_type_the_fp16_selection(world):
+    """VideoEncoder(selection_refine) - automatic under bf16 DINOv2 operands: when the similarity ranks that decide the a5 selection
+    are closer than 2 selection_eps, the pairs inside that band, and only they, are re-encoded by the fp16-operand copy of the
+    tower and re-ranked.  On the slow-drift video, for EVERY boundary rank 4 ... 200: the refined selection of the bench type is
+    exactly what ranking the fp16 / fp16 tower's similarities selects (the reference's own arithmetic, tdc/builder.py:69), at the
+    price of a few dozen re-encoded frames; and the whole path (encode_video) does it by itself."""
+    import bench
+    from tdc_video_amd import segment as seg
+    enc, sims_of, video = world
+    assert enc.selection_eps == 1e-3 and "dino_precise" in enc.towers and enc.towers["dino_precise"]["dtype"] == torch.float16
+    feat_b = enc.tower("dino", video)
+    s_b = enc.sims_tensor(feat_b, T).cpu().tolist()
+    feat_p = enc.precise_dino(video)
+    s_p = enc.sims_tensor(feat_p, T).cpu().tolist()
+    assert s_p == sims_of(video, torch.float16, torch.float16)                       # the precise tower IS the fp16 / fp16 form
+    err = max(abs(a - b) for a, b in zip(s_b, s_p))
+    assert err < 0.6 * enc.selection_eps, err                                        # measured 3.7e-4 against the assumed 1e-3
+    P = feat_p.shape[0] // T
+    rows = {f: feat_p[f * P:(f + 1) * P] for f in range(T)}
+    sizes, changed = [], 0
+    for m in range(4, 201):
+        band = seg.selection_band(s_b, m, enc.selection_eps)
+        refined = enc.pair_sims(rows, [(i, i + 1) for i in band]).tolist() if band else []
+        assert refined == [s_p[i] for i in band]                                     # pair_sims == the a5 kernel on the same rows
+        got = seg.select_refined(s_b, m, enc.selection_eps, band, refined)
+        assert got == seg.select_segments(s_p, m), m
+        changed += got != seg.select_segments(s_b, m)
+        sizes.append(len(seg.band_frames(band)))
+    print("refinement on the slow-drift video: similarity error of the bench type %.2e (bound %.0e); boundary ranks 4..200: the "
+          "refined selection equals the fp16 tower's at all 197, differs from the unrefined one at %d; frames re-encoded per call: "
+          "median %d, max %d of %d" % (err, enc.selection_eps, changed, int(np.median(sizes)), max(sizes), T))
+    assert changed >= 10 and max(sizes) < T // 4
+    # the re-encoded subset equals the rows of the full run bit for bit (tower-batch invariance), and encode_video runs it by itself
+    band = seg.selection_band(s_b, 24, enc.selection_eps)
+    frames = seg.band_frames(band)
+    sub = enc.precise_dino(video[torch.tensor(frames, device=video.device)])
+    assert torch.equal(sub, torch.cat([rows[f] for f in frames], 0))
+    vs = bench.synth_video(0, T, 384, video.device, torch.bfloat16)
+    info = {}
+    out = enc.encode_video(vs, video, (384, 384), budget_text_len=64, n_text_tokens=64, prompt_ids=[101, 2000, 102], frame_cap=T,
+                           info=info)
+    assert info["refined_pairs"] == band and len(band) >= 2
+    assert info["seg_indices"] == seg.select_segments(s_p, 24)
+    enc.selection_eps = None                                                         # refinement off: the bench type's own ranking
+    info2 = {}
+    out2 = enc.encode_video(vs, video, (384, 384), budget_text_len=64, n_text_tokens=64, prompt_ids=[101, 2000, 102], frame_cap=T,
+                            info=info2)
+    enc.selection_eps = 1e-3
+    assert info2["refined_pairs"] == [] and info2["seg_indices"] == seg.select_segments(s_b, 24)
+    assert torch.isfinite(out.float()).all() and (info["seg_indices"] == info2["seg_indices"]) == torch.equal(out, out2)
