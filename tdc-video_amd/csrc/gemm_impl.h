@@ -1009,6 +1009,12 @@ __device__ __forceinline__ void epi_staged32(const GemmArgs& p, f32x4 (&acc)[8][
 #ifndef TDC_RMW16_RING
 #define TDC_RMW16_RING 8      // residual loads in flight per wave (of the 16 a 128 x 64 sub-tile needs)
 #endif
+#ifndef TDC_RMW32_FOLD_RING
+#define TDC_RMW32_FOLD_RING 4 // fp32 read-modify-write in the fold form
+#endif
+#ifndef TDC_RMW16_FOLD_RING
+#define TDC_RMW16_FOLD_RING 6 // ... in the fold form (fp8 operands)
+#endif
 // a += float(r[0..3]), b += float(r[4..7]) for eight 16-bit residual values.  fp16: one v_fma_mix_f32 per element (the
 // half of the packed register converted on the fly, x 1.0, + the fp32 sum) instead of a conversion per element and a packed
 // add per pair - 8 instead of 12 instructions per eight values, the same correctly rounded fp32 sum (the conversion is exact).
@@ -1156,9 +1162,14 @@ __device__ __forceinline__ bool epilogue_staged_f(const GemmArgs& p, f32x4 (&acc
             return true;
         }
     }
-    if (FOLD && p.out_f32 && res == 1 && p.act == TDC_ACT_NONE) {      // fp8 operands of a residual-stream GEMM
-        epi_staged32<T, 1, R32, SMALL, false, true>(p, acc, region, mbase, nbase, lane, el);
-        return true;
+    // fp8 operands of a residual-stream GEMM (fp32 stream here, 16-bit stream below): the fold + residual forms exist for the e4m3
+    // instantiations only (kScaleOnly: gemm_fp8.hip) - the host refuses them for 16-bit operands, and compiled into the 16-bit
+    // LayerNorm-fold instance they only cost it registers
+    if constexpr (FOLD && kScaleOnly) {
+        if (p.out_f32 && res == 1 && p.act == TDC_ACT_NONE) {
+            epi_staged32<T, 1, R32, SMALL, false, true, TDC_RMW32_FOLD_RING>(p, acc, region, mbase, nbase, lane, el);
+            return true;
+        }
     }
     if (p.out_f32 || res == 1 || (p.ldc & 7) || ((uintptr_t)p.C & 15)) return false;
     if (p.act == TDC_ACT_SWIGLU) {
@@ -1172,9 +1183,12 @@ __device__ __forceinline__ bool epilogue_staged_f(const GemmArgs& p, f32x4 (&acc
     else if (res == 2) {
         if ((p.N & 7) || (p.ldres & 7) || ((uintptr_t)p.res & 15)) return false;
         constexpr int RR = SMALL ? 16 : 32;
+        if constexpr (FOLD && !kScaleOnly) return false;
         if constexpr (FOLD) {    // fp8 operands of a residual-stream GEMM over a 16-bit stream (scales through the fold operands)
-            if (p.ctype == TDC_F16) epi_staged_rmw16<f16, RR, SMALL, TDC_RMW16_RING, false, true>(p, acc, region, mbase, nbase, lane, el);
-            else epi_staged_rmw16<bf16, RR, SMALL, TDC_RMW16_RING, false, true>(p, acc, region, mbase, nbase, lane, el);
+            // (ring of 4 residual loads instead of 8: the fold's row / column operands take 32 registers of their own; rings of 4-8
+            //  measured equal on the plain form, profiles/r04_gemm_rmw16_ring_ab.log)
+            if (p.ctype == TDC_F16) epi_staged_rmw16<f16, RR, SMALL, TDC_RMW16_FOLD_RING, false, true>(p, acc, region, mbase, nbase, lane, el);
+            else epi_staged_rmw16<bf16, RR, SMALL, TDC_RMW16_FOLD_RING, false, true>(p, acc, region, mbase, nbase, lane, el);
             return true;
         }
         if (p.ln_part) {         // producer of the LayerNorm fold over a 16-bit stream

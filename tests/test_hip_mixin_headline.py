@@ -123,7 +123,8 @@ def test_config_keys_are_validated(world):
     keep = m._tdc_encoder
     try:
         for key, bad in (("tdc_tower_dtype", "float8"), ("tdc_tower_dtype", "float32"), ("tdc_dino_dtype", "double"),
-                         ("tdc_tower_res_dtype", "fp64"), ("tdc_tower_batch", -1), ("tdc_tower_batch", "64")):
+                         ("tdc_tower_res_dtype", "fp64"), ("tdc_tower_batch", -1), ("tdc_tower_batch", "64"),
+                         ("tdc_selection_refine", "yes"), ("tdc_selection_eps", 2), ("tdc_selection_eps", "1e-3")):
             old = getattr(cfg, key, None)
             setattr(cfg, key, bad)
             with pytest.raises(ValueError, match=key):
