@@ -37,8 +37,11 @@ class Lin:
 
 def make_lin(W, b, dtype, dev, row_scale=None, col_scale=None, col_shift=None, n_pad=None, k_pad=None):
     """W [n,k].  Effective op: y = row_scale * (W @ (col_scale * x + col_shift) + b).  The folding arithmetic runs in
-    fp32 on whatever device W lives on (one-time weight preparation), the result is cast and moved to `dev`."""
+    fp32 (one-time weight preparation) on `dev` when that is a GPU - host weights are uploaded first: padding and converting
+    1.5 G parameters is seconds of host time otherwise - else on the device W lives on; the result is cast and moved to `dev`."""
     W = W.detach().to(torch.float32)
+    if W.device.type == "cpu" and torch.device(dev).type == "cuda":
+        W = W.to(dev)
     wd = W.device
     n, k = W.shape
     bias = b.detach().to(torch.float32).to(wd).clone() if b is not None else None
@@ -72,10 +75,11 @@ def stack_lins(parts, dtype, dev, k_pad=None, n_pad=None):
     any_b = any(p[1] is not None or (p[2] or {}).get("col_shift") is not None for p in parts)
     for W, b, kw in parts:
         kw = kw or {}
-        l = make_lin(W, b, torch.float32, W.device, n_pad=W.shape[0], k_pad=W.shape[1], **kw)
+        l = make_lin(W, b, torch.float32, dev if torch.device(dev).type == "cuda" else W.device, n_pad=W.shape[0],
+                     k_pad=W.shape[1], **kw)
         Ws.append(l.w)
         if any_b:
-            bs.append(l.b if l.b is not None else torch.zeros(W.shape[0], device=W.device))
+            bs.append(l.b if l.b is not None else torch.zeros(W.shape[0], device=l.w.device))
     Wc = torch.cat(Ws, 0)
     bc = torch.cat(bs, 0) if any_b else None
     return make_lin(Wc, bc, dtype, dev, k_pad=k_pad, n_pad=n_pad)
