@@ -373,7 +373,8 @@ class CambrianMetaModel:
         tdc_frame_cap=T (its `product_setting` field says so; `bench.py --via-mixin` runs exactly that)."""
         if self._tdc_encoder is None or refresh:
             cfg = {k: getattr(self.config, k) for k in dir(self.config)
-                   if not k.startswith("_") and isinstance(getattr(self.config, k, None), (int, float, str, bool, list))}
+                   if not k.startswith("_") and (isinstance(getattr(self.config, k, None), (int, float, str, bool, list)) or
+                                                 (k.startswith("tdc_") and isinstance(getattr(self.config, k, None), torch.dtype)))}
             device = device or ("cuda:%d" % torch.cuda.current_device())
             dtype = dtype or (self.dtype if self.dtype in (torch.float16, torch.bfloat16) else torch.float16)
             towers = self.vision_tower_aux_list
