@@ -34,20 +34,20 @@ def select_segments(sims, max_num_segments=24):
 def selection_band(sims, max_num_segments, eps):
     """Which adjacent-frame similarities must be known more precisely before the a5 selection (tdc/cambrian_arch.py:849) can be
     trusted, when `sims` are within `eps` of the values a more precise tower would give (bf16 DINOv2 operands against the
-    reference's fp16: measured 3.7e-4 ... 4.2e-4).
-    With v_n / v_n1 the n-th and (n+1)-th smallest value (n = max_num_segments): if v_n1 - v_n > 2 eps no error of that size can
-    swap a selected pair with an unselected one - the selection is already the precise one, and [] is returned.  Otherwise every
-    index with v_n - 2 eps <= sims[i] <= v_n1 + 2 eps is returned (ascending): pairs below that band are selected whatever their
-    precise values are, pairs above it never are (at least n + 1 values are smaller by more than the error), so only the band has
-    to be re-ranked (`select_refined`)."""
+    reference's fp16: measured 3.6e-4 ... 4.2e-4).
+    With v_n / v_n1 the n-th and (n+1)-th smallest value (n = max_num_segments): a pair with sims[i] < v_n1 - 2 eps is selected
+    whatever its precise value is (every pair that could precede it precisely has sims < v_n1, and there are at most n of those,
+    itself included); a pair with sims[i] > v_n + 2 eps never is (the n pairs with sims <= v_n are all precisely smaller).  What
+    is left, v_n1 - 2 eps <= sims[i] <= v_n + 2 eps, is returned (ascending) and has to be re-ranked (`select_refined`); when
+    v_n1 - v_n > 4 eps the interval is empty: no error of that size can swap a selected pair with an unselected one."""
     n = len(sims)
     if n <= max_num_segments or eps is None or eps <= 0:
         return []
     order = sorted(range(n), key=lambda i: (sims[i], i))
     v_n, v_n1 = sims[order[max_num_segments - 1]], sims[order[max_num_segments]]
-    if v_n1 - v_n > 2.0 * eps:
+    lo, hi = v_n1 - 2.0 * eps, v_n + 2.0 * eps
+    if lo > hi:
         return []
-    lo, hi = v_n - 2.0 * eps, v_n1 + 2.0 * eps
     return [i for i in range(n) if lo <= sims[i] <= hi]
 
 
@@ -55,14 +55,15 @@ def select_refined(sims, max_num_segments, eps, band, refined):
     """The selection after the band's similarities were recomputed precisely (`refined[j]` belongs to pair `band[j]`): every pair
     below the band, plus the lowest of the band by (refined value, index) - the stable ranking of select_segments - up to
     max_num_segments.  With refined == the precise tower's values this is exactly what ranking ALL of that tower's similarities
-    selects, as long as |sims - precise| <= eps."""
+    selects, as long as |sims - precise| <= eps (the precise top-n is a prefix of the precise order, so what it takes from the
+    band is a prefix of the band's order)."""
     if not band:
         return select_segments(sims, max_num_segments)
     assert len(band) == len(refined)
     inband = set(band)
     order = sorted(range(len(sims)), key=lambda i: (sims[i], i))
-    v_n = sims[order[max_num_segments - 1]]
-    low = [i for i in range(len(sims)) if sims[i] < v_n - 2.0 * eps and i not in inband]
+    v_n1 = sims[order[max_num_segments]]
+    low = [i for i in range(len(sims)) if sims[i] < v_n1 - 2.0 * eps and i not in inband]
     need = max_num_segments - len(low)
     assert 0 <= need <= len(band), (need, len(band), len(low))
     ranked = sorted(range(len(band)), key=lambda j: (refined[j], band[j]))[:need]
