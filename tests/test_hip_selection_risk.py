@@ -146,6 +146,19 @@ def test_refinement_gives_the_bench_type_the_fp16_selection(world):
     assert s_p == sims_of(video, torch.float16, torch.float16)                       # the precise tower IS the fp16 / fp16 form
     err = max(abs(a - b) for a, b in zip(s_b, s_p))
     assert err < 0.6 * enc.selection_eps, err                                        # measured 3.7e-4 against the assumed 1e-3
+    # the bound the refinement rests on, on other kinds of video: scenes with cuts (the bench's), independent noise frames
+    # (similarities near 0.5), a near-static clip (similarities near 1)
+    gg = torch.Generator(device=video.device).manual_seed(3)
+    base = torch.rand(3, 378, 378, device=video.device, generator=gg) * 2 - 1
+    others = {"scenes + cuts (bench video)": bench.synth_video(0, 128, 378, video.device, torch.bfloat16, seed=4321),
+              "independent noise frames": (torch.rand(128, 3, 378, 378, device=video.device, generator=gg) * 2 - 1).half(),
+              "near-static clip": (base[None] + 0.02 * torch.randn(128, 3, 378, 378, device=video.device, generator=gg)).half()}
+    for name, v in others.items():
+        sb = enc.sims_tensor(enc.tower("dino", v), v.shape[0]).cpu()
+        sp = enc.sims_tensor(enc.precise_dino(v), v.shape[0]).cpu()
+        e = float((sb - sp).abs().max())
+        print("similarity error of the bench type on %-30s %.2e (similarities %.3f ... %.3f)" % (name + ":", e, float(sp.min()), float(sp.max())))
+        assert e < 0.6 * enc.selection_eps, (name, e)
     P = feat_p.shape[0] // T
     rows = {f: feat_p[f * P:(f + 1) * P] for f in range(T)}
     sizes, changed = [], 0
