@@ -60,8 +60,8 @@ class VideoEncoder:
         precision (3.4e-5 instead of 4.2e-4 with bf16 operands) while SigLIP stays in tower_dtype.
         selection_refine (None = automatic: on when the DINOv2 operands are bf16 and not e4m3) / selection_eps: the a5 segment
         selection at the reference's precision under bf16 DINOv2 operands.  bf16 similarities are within selection_eps of the fp16
-        tower's (measured 3.7e-4 ... 4.2e-4; default bound 1e-3); when the ranks that decide the selection are closer than
-        2 selection_eps, the pairs inside that band - and only they - are re-encoded by a second, fp16-operand copy of the DINOv2
+        tower's (measured 1.7e-4 ... 5.0e-4; default bound 1e-3); when the ranks that decide the selection are closer than
+        4 selection_eps, the pairs inside the band [v_n+1 - 2 eps, v_n + 2 eps] - and only they - are re-encoded by a second, fp16-operand copy of the DINOv2
         tower (+2.2 GB of weights) and re-ranked (segment.selection_band / select_refined): exactly what ranking the fp16 tower's
         similarities selects.  A video whose decisive ranks are further apart (the bench's: 0.43) pays nothing.
         fp8_towers (BASELINE config 5): the towers' LayerNorms emit e4m3 rows with per-row scales and the qkv / fc1 GEMMs

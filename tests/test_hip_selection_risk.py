@@ -131,7 +131,7 @@ def test_selection_risk_of_the_dino_operand_type(world):
 
 def test_refinement_gives_the_bench_type_the_fp16_selection(world):
     """VideoEncoder(selection_refine) - automatic under bf16 DINOv2 operands: when the similarity ranks that decide the a5 selection
-    are closer than 2 selection_eps, the pairs inside that band, and only they, are re-encoded by the fp16-operand copy of the
+    are closer than 4 selection_eps, the pairs inside the band around them, and only they, are re-encoded by the fp16-operand copy of the
     tower and re-ranked.  On the slow-drift video, for EVERY boundary rank 4 ... 200: the refined selection of the bench type is
     exactly what ranking the fp16 / fp16 tower's similarities selects (the reference's own arithmetic, tdc/builder.py:69), at the
     price of a few dozen re-encoded frames; and the whole path (encode_video) does it by itself."""
