@@ -132,6 +132,11 @@ def build_mixin_lm(cfg, sd, dev, dtype, extra=None, vocab=2048):
                                mm_projector_type="sva", connector_only=True, tokenizer_padding_side="right", **cfg)
     for k, v in (extra or {}).items():
         setattr(ns, k, v)
+    # SigLIP's learned position table follows the input size (336 px: 24 x 24 positions instead of 27 x 27)
+    from tdc_video_amd.model import SIGLIP_SO400M
+    n_pos = sd["vision_tower_aux_list.0.vision_tower.embeddings.position_embedding.weight"].shape[0]
+    if n_pos != SIGLIP_SO400M["n_pos"]:
+        ns.tdc_tower_archs = {"siglip": dict(SIGLIP_SO400M, n_pos=n_pos)}
 
     class StubBase(nn.Module):
         def __init__(self, config):
