@@ -178,8 +178,11 @@ def test_fullsize_towers_vs_oracle(full_sd, dtype, tol, fuse, monkeypatch):
 # At K = 16 the shapes differ in kind: S = K + Lt = 28 rows per frame in the self-attention, F * K of a few hundred rows in the
 # row-mapped query GEMMs (fewer 256 x 256 tiles than CUs on the persistent kernel), a ragged last 64-row block in the fused
 # cross-attention output kernel.  mns = max_num_segments: 24 leaves 7 compressed frames of the 32, 3 leaves ~26.
-@pytest.mark.parametrize("K,mns", [(144, 24), (16, 24), (16, 3)])
-def test_fullsize_connector_compressor_vs_oracle(full_sd, K, mns):
+# size: the frames' (H, W) as the caller passes it.  (360, 640) is a 16:9 video: the SVA's window masks exclude the padding rows of
+# the squared frame (tdc/cambrian_arch.py:619-669), the unpad - which reads the pair as (W, H), SURVEY D8 - keeps 6 of the 12 token
+# COLUMNS (:512-544) and the Q-Former sees N = 12 x (6 + 1) = 84 encoder tokens per frame - the a7 / a10 geometry at full width
+@pytest.mark.parametrize("K,mns,size", [(144, 24, (384, 384)), (16, 24, (384, 384)), (16, 3, (384, 384)), (16, 3, (360, 640))])
+def test_fullsize_connector_compressor_vs_oracle(full_sd, K, mns, size):
     """S4-S10 at BASELINE sizes (C=1024, H=3584, 12-layer Q-Former) on a 32-frame clip of tower features:
     emitted tokens vs the oracle; compressed (unit-norm) rows within the north_star's 1e-3 fp16 atol."""
     import tdc_video_amd  # noqa: F401
@@ -196,12 +199,13 @@ def test_fullsize_connector_compressor_vs_oracle(full_sd, K, mns):
     din = torch.randn(T, 576, 1536, generator=g).half().float()
     pid = [101] + list(range(2000, 2010)) + [102]
     with torch.no_grad():
-        if "s4_s7" not in _ORACLE_CACHE:       # connector stages do not depend on K / mns: one run of the fp32 oracle
-            aux = [orc.mm_projector_aux(sig, W, 0), orc.mm_projector_aux(din, W, 1)]
-            q, _ = orc.sva(aux, W["vision_query"][0], [(384, 384)] * T, W, 12)
+        if ("s4_s7", size) not in _ORACLE_CACHE:       # connector stages do not depend on K / mns: one run of the fp32 oracle per size
+            if "aux" not in _ORACLE_CACHE:
+                _ORACLE_CACHE["aux"] = [orc.mm_projector_aux(sig, W, 0), orc.mm_projector_aux(din, W, 1)]
+            q, _ = orc.sva(_ORACLE_CACHE["aux"], W["vision_query"][0], [size] * T, W, 12)
             feat = orc.mm_projector(q, W)
-            _ORACLE_CACHE["s4_s7"] = (orc.unpad_newline(feat, [(384, 384)] * T, W["image_newline"])[0], orc.adjacent_cosine(din))
-        frames, sims_ref = _ORACLE_CACHE["s4_s7"]
+            _ORACLE_CACHE[("s4_s7", size)] = (orc.unpad_newline(feat, [size] * T, W["image_newline"])[0], orc.adjacent_cosine(din))
+        frames, sims_ref = _ORACLE_CACHE[("s4_s7", size)]
         segi = orc.select_segments(sims_ref, mns)
         want = orc.tdc_compress(torch.stack(frames), segi, torch.tensor(pid), W, K, 12, 10 ** 9)
     from tdc_video_amd.weights import pad64
@@ -210,7 +214,8 @@ def test_fullsize_connector_compressor_vs_oracle(full_sd, K, mns):
         buf[:, :D] = x.reshape(-1, D).half().cuda()
         return buf
     keep = {}
-    X, _ = enc.connector(pad(sig, 1152), pad(din, 1536), T, [(384, 384)] * T, keep)
+    X, fsz = enc.connector(pad(sig, 1152), pad(din, 1536), T, [size] * T, keep)
+    assert X.shape[0] // T == frames[0].shape[0] == (156 if size == (384, 384) else 84), (X.shape, frames[0].shape)
     sims = enc.sims_tensor(pad(din, 1536), T).tolist()
     assert seg.select_segments(sims, mns) == [int(i) for i in segi]
     got = enc.compress(X, T, X.shape[0] // T, [int(i) for i in segi], pid, 10 ** 9, keep=keep)
@@ -222,8 +227,8 @@ def test_fullsize_connector_compressor_vs_oracle(full_sd, K, mns):
     assert len(plan["comp_frames"]) == T - len(plan["chunks"]) and len(plan["comp_frames"]) >= (7 if mns == 24 else 20)
     err_c = float((got[comp_rows].float().cpu() - want[comp_rows]).abs().max())
     err_s = _rel(got[stat_rows], want[stat_rows])
-    print("full-size K=%d mns=%d (%d compressed frames): compressed-token max abs err %.3e (unit-norm rows), static rows rel %.3e"
-          % (K, mns, len(plan["comp_frames"]), err_c, err_s))
+    print("full-size K=%d mns=%d frames %s (%d compressed frames, N = %d): compressed-token max abs err %.3e (unit-norm rows), static "
+          "rows rel %.3e" % (K, mns, size, len(plan["comp_frames"]), X.shape[0] // T, err_c, err_s))
     assert err_c < 1e-3, err_c
     assert err_s < 8e-4, err_s          # measured 4.7e-4
 
