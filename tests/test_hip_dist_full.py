@@ -154,3 +154,48 @@ def test_fullsize_sharded_world8_threads_equal_serial(per_rank):
         assert got[r].shape == want.shape and torch.equal(got[r], want), "rank %d of 8 differs" % r
     del engines
     torch.cuda.empty_cache()
+
+
+def _drift(lo, hi, T, px=378):
+    """frames [lo, hi) of a slow-drift video (f_t = cos(theta_t) A + sin(theta_t) B, irregular steps): adjacent-frame similarities
+    spread densely enough that the ranks deciding the a5 selection are closer than the bf16 operands' error band"""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device=dev).manual_seed(99)
+    A = torch.rand(3, px, px, device=dev, generator=g) * 2 - 1
+    B = torch.rand(3, px, px, device=dev, generator=g) * 2 - 1
+    steps = 0.03 + 0.02 * torch.rand(T - 1, device=dev, generator=g)
+    th = torch.cat([torch.zeros(1, device=dev), torch.cumsum(steps, 0)])[lo:hi]
+    return (torch.cos(th)[:, None, None, None] * A[None] + torch.sin(th)[:, None, None, None] * B[None]).to(torch.bfloat16)
+
+
+def test_fullsize_sharded_selection_refinement_equals_serial():
+    """The a5 selection refinement (bf16 DINOv2 operands: automatic) in the sharded path with the real engine: a near-tied video,
+    world 4 (threads), 32 frames per rank.  The band of pairs to re-rank is a host decision on the all-gathered similarities; a pair
+    belongs to the rank owning its first frame, a pair across a rank boundary gets the right neighbour's precise boundary features,
+    the refined values are all-gathered - and every rank emits the serial stream bit for bit, with the serial selection."""
+    from test_hip_dist2 import run_threads
+    from tdc_video_amd import segment as seg
+    from tdc_video_amd.dist import ShardedVideoEncoder
+    world, T = 4, 128
+    engines = [_engine(T)[0] for _ in range(world)]
+    assert all(e.selection_eps == 1e-3 and "dino_precise" in e.towers for e in engines)
+    info = {}
+    want = engines[0].encode_video(_video(0, T, 384, 1234), _drift(0, T, T), (384, 384), budget_text_len=64, n_text_tokens=64,
+                                   prompt_ids=PROMPT, frame_cap=T, info=info)
+    band = info["refined_pairs"]
+    ranges = seg.shard_ranges(T, world)
+    print("sharded refinement: %d pairs in the band, %d across a rank boundary; selection changed by the refinement: %s"
+          % (len(band), sum(1 for (l, h) in ranges[:-1] if (h - 1) in band),
+             info["seg_indices"] != seg.select_segments(engines[0].sims_tensor(engines[0].tower("dino", _drift(0, T, T)), T).tolist(), 24)))
+    assert len(band) >= 2
+
+    def rank_run(r, comm):
+        sh = ShardedVideoEncoder(engines[r], r, world, comm=comm)
+        fp = sh.frame_plan(T, budget_text_len=64, frame_cap=T)
+        return sh.encode_video(_video(fp["lo"], fp["hi"], 384, 1234), _drift(fp["lo"], fp["hi"], T), T, (384, 384), 64, PROMPT,
+                               sample_indices=fp["sample_indices"])
+    got = run_threads(world, rank_run)
+    for r in range(world):
+        assert got[r].shape == want.shape and torch.equal(got[r], want), "rank %d of %d differs" % (r, world)
+    del engines
+    torch.cuda.empty_cache()
