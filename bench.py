@@ -734,7 +734,8 @@ def main():
                    "emitted_tokens": int(out.shape[0]) - (64 if lm is not None else 0),
                    "selection_refine": {"on": enc.selection_eps is not None, "eps": enc.selection_eps,
                                         "note": "a5 under bf16 DINOv2 operands: pairs whose similarities decide the selection and lie within "
-                                                "2 eps of the decisive ranks are re-encoded by an fp16-operand DINOv2 tower; none on this video"}},
+                                                "2 eps of the decisive ranks are re-encoded by an fp16-operand DINOv2 tower (bands of more than "
+                                                "max(8, frames / 8) frames - plateaus - are left alone); none at T = 512 on this video"}},
         "rank_ms_per_step": None if rank_ms is None else {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
         "ranks_seen": ranks_seen, "rank_devices": rank_devices if world > 1 else [local],
         "dist_backend": (os.environ.get("TDC_DIST_BACKEND", "nccl") + " (RCCL)" * (os.environ.get("TDC_DIST_BACKEND", "nccl") == "nccl")) if world > 1 else None,

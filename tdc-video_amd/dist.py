@@ -308,7 +308,7 @@ class ShardedVideoEncoder:
             seg_idx = seg.select_segments(sims, mns)
             eps = getattr(e, "selection_eps", None)
             band = seg.selection_band(sims, mns, eps) if eps else []         # host integers: identical on every rank
-            if band:
+            if band and seg.band_allowed(band, T, getattr(e, "selection_max_fraction", 0.125)):
                 seg_idx = self._refine_selection(band, sims, mns, eps, px_dino_local_halo, ranges, recompute_halo)
         dino = dino_all[: Tl * P]
         # 2. local towers + connector (+ audio rows of the local frames)

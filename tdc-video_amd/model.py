@@ -359,7 +359,8 @@ class CambrianMetaModel:
         `config.tdc_selection_refine` (default: automatic - on when the DINOv2 operands are bf16) / `config.tdc_selection_eps`
         (default 1e-3): the a5 segment selection at the reference's precision under bf16 DINOv2 operands - the pairs whose
         similarities decide the selection and lie closer than the operand type's error are re-encoded by an fp16-operand copy of
-        the DINOv2 tower (VideoEncoder.selection_refine; DESIGN.md section 2);
+        the DINOv2 tower, as long as their frames number at most max(8, `config.tdc_selection_max_fraction` (default 1/8) x frames)
+        (VideoEncoder.selection_refine; DESIGN.md section 2);
         `config.tdc_tower_res_dtype = "float16" | "bfloat16" | "float32"`: the towers' residual stream in HBM.  Default:
         "float16" when the towers' operands are fp16 - the reference's own arithmetic, its HF towers run under
         torch_dtype=float16 (tdc/builder.py:69) -, "float32" otherwise (bf16 operands reach 3e38, an fp16 stream ends at 65504:
@@ -393,6 +394,9 @@ class CambrianMetaModel:
             sel_eps = cfg.get("tdc_selection_eps", 1e-3)
             if isinstance(sel_eps, bool) or not isinstance(sel_eps, (int, float)) or not (0 < sel_eps < 1):
                 raise ValueError("config.tdc_selection_eps must be a similarity error bound in (0, 1), got %r" % (sel_eps,))
+            sel_frac = cfg.get("tdc_selection_max_fraction", 0.125)
+            if isinstance(sel_frac, bool) or not isinstance(sel_frac, (int, float)) or not (0 <= sel_frac <= 1):
+                raise ValueError("config.tdc_selection_max_fraction must be a fraction of the frames in [0, 1], got %r" % (sel_frac,))
             tb = cfg.get("tdc_tower_batch")
             if tb is not None and (isinstance(tb, bool) or not isinstance(tb, int) or tb < 0):
                 raise ValueError("config.tdc_tower_batch must be a positive frame count (or 0 / absent for the automatic "
@@ -403,6 +407,7 @@ class CambrianMetaModel:
                                              tower_batch=tb or None, tower_dtype=tower_dtype, dino_dtype=dino_dtype,
                                              ln_fuse=bool(cfg.get("tdc_ln_fuse", False)),
                                              selection_refine=sel_refine, selection_eps=sel_eps,
+                                             selection_max_fraction=sel_frac,
                                              tower_res_dtype=res)
         return self._tdc_encoder
 

@@ -49,7 +49,7 @@ class _LRU(dict):
 class VideoEncoder:
     def __init__(self, sd, cfg, dtype=torch.float16, device="cuda", siglip_heads=16, dino_heads=24,
                  qformer_heads=12, tower_batch=None, fp8_towers=False, tower_dtype=None, ln_fuse=False,
-                 tower_res_dtype=None, dino_dtype=None, selection_refine=None, selection_eps=1e-3):
+                 tower_res_dtype=None, dino_dtype=None, selection_refine=None, selection_eps=1e-3, selection_max_fraction=0.125):
         """sd: reference-named state dict without the leading 'model.'; cfg: dict of reference config keys.
         dtype: 16-bit type of the connector, the Q-Former and every tensor handed to the caller; tower_dtype (default:
         dtype): 16-bit type of the two ViT towers - their last kernel (the token-grid resample) writes `dtype` rows.  bf16
@@ -63,7 +63,9 @@ class VideoEncoder:
         tower's (measured 1.7e-4 ... 5.0e-4; default bound 1e-3); when the ranks that decide the selection are closer than
         4 selection_eps, the pairs inside the band [v_n+1 - 2 eps, v_n + 2 eps] - and only they - are re-encoded by a second, fp16-operand copy of the DINOv2
         tower (+2.2 GB of weights) and re-ranked (segment.selection_band / select_refined): exactly what ranking the fp16 tower's
-        similarities selects.  A video whose decisive ranks are further apart (the bench's: 0.43) pays nothing.
+        similarities selects.  A video whose decisive ranks are further apart (the bench's: 0.43) pays nothing; a band whose
+        frames exceed max(8, selection_max_fraction x frames) - a plateau of near-identical similarities at the decisive rank, where
+        the reference's own fp16 similarity values tie - is left to the fast tower's ranking (segment.band_allowed).
         fp8_towers (BASELINE config 5): the towers' LayerNorms emit e4m3 rows with per-row scales and the qkv / fc1 GEMMs
         run on fp8 operands (v_mfma_f32_16x16x128_f8f6f4); everything else stays in `tower_dtype`.
         ln_fuse: the towers' pre-LayerNorms folded into the neighbouring GEMMs (weights.ln_fusion_enabled; off by default).
@@ -110,6 +112,7 @@ class VideoEncoder:
             tp["res_dtype"] = torch.float16 if self.tower_res_dtype is not None else None
             self.towers["dino_precise"] = tp
             self.selection_eps = float(selection_eps)
+        self.selection_max_fraction = float(selection_max_fraction)
         self.c = Wt.prep_connector(sd, cfg, dtype, self.dev)
         tok = cfg.get("mm_vision_tower_aux_token_len_list", [576, 576])
         self.out_grid = [int(round(t ** 0.5)) for t in tok]
@@ -985,6 +988,10 @@ def encode_video_with(e, px_siglip, px_dino, image_size, budget_text_len, n_text
         # the ranks that decide the selection are closer than the operand type's error, the pairs in that band are re-encoded
         eps = getattr(e, "selection_eps", None)
         band = seg.selection_band(sims, mns, eps) if eps else []
+        if band and not seg.band_allowed(band, T, getattr(e, "selection_max_fraction", 0.125)):
+            if info is not None:
+                info["refine_skipped_pairs"] = len(band)      # a plateau at the decisive rank: the fast tower's ranking stands
+            band = []
         if band:
             frames = seg.band_frames(band)
             pxd = px_dino if len(sel2) == px_dino.shape[0] else px_dino[torch.tensor(sel2, device=px_dino.device)]

@@ -70,6 +70,15 @@ def select_refined(sims, max_num_segments, eps, band, refined):
     return sorted(low + [band[j] for j in ranked])
 
 
+def band_allowed(band, T, max_fraction):
+    """Cost control of the refinement: the band's frames are re-encoded by a second tower, so a band that covers a large part of the
+    video - a plateau of near-identical similarities at the decisive rank, e.g. a clip with fewer real scene changes than
+    max_num_segments - would cost a large part of a tower pass to settle an order the reference itself does not define there (it ranks
+    fp16 similarity VALUES, spaced 4.9e-4 in [0.5, 1), with an argsort that promises nothing among equal ones:
+    tdc/cambrian_arch.py:841,849).  The band is refined when its frames number at most max(8, max_fraction * T)."""
+    return bool(band) and len(band_frames(band)) <= max(8, int(max_fraction * T))
+
+
 def band_frames(band):
     """frames whose precise features the band's pairs need: pair i = frames (i, i + 1); ascending, no duplicates"""
     return sorted({f for i in band for f in (i, i + 1)})

@@ -89,6 +89,7 @@ class NoisyEngine(FakeEngine):
     which offers the precise tower for the a5 selection refinement (segment.selection_band / select_refined): the per-frame
     perturbation moves the adjacent-frame similarities by less than selection_eps."""
     selection_eps = 2e-3
+    selection_max_fraction = 1.0         # these cases refine wide bands on purpose (the product's default caps them at 1/8)
 
     def precise_dino(self, px):
         return FakeEngine.tower(self, "dino", px)
@@ -292,6 +293,37 @@ def test_selection_band_property():
         assert seg.select_refined(noisy, mns, eps, band, [ref[i] for i in band]) == seg.select_segments(ref, mns)
     assert seg.selection_band([0.1, 0.2, 0.5, 0.9], 2, 0.01) == [] and seg.selection_band([0.1, 0.2], 2, 0.01) == []
     assert seg.selection_band([0.1, 0.2, 0.21, 0.9], 2, 0.01) == [1, 2] and seg.band_frames([1, 2, 7]) == [1, 2, 3, 7, 8]
+    # the cost cap: a band is refined when its frames number at most max(8, fraction x T)
+    assert seg.band_allowed([1, 2, 7], 512, 0.125) and seg.band_allowed(list(range(0, 63)), 512, 0.125)
+    assert not seg.band_allowed(list(range(0, 64)), 512, 0.125) and not seg.band_allowed([], 512, 0.125)
+    assert seg.band_allowed([3, 4, 5, 6, 7, 8, 9], 40, 0.125) and not seg.band_allowed(list(range(3, 11)), 40, 0.125)
+
+
+def test_selection_refinement_is_capped_on_a_plateau():
+    """a clip with fewer scene changes than max_num_segments: the decisive rank lies in a plateau of near-identical similarities, the
+    band covers most of the video - beyond the cap the fast tower's ranking stands (serial and sharded alike)"""
+    eng, vid, audio, cap = _case("refine61")
+    eng.selection_max_fraction = 0.125
+    info = {}
+    want = pipeline.encode_video_with(eng, vid, vid, (384, 384), budget_text_len=4, n_text_tokens=4, prompt_ids=[1, 2], frame_cap=cap,
+                                      info=info)
+    noisy = eng.sims_tensor(eng.tower("dino", vid), 61).tolist()
+    assert info["refined_pairs"] == [] and info["refine_skipped_pairs"] > 8 and info["seg_indices"] == seg.select_segments(noisy, 24)
+    import threading
+    from util import ThreadComm
+    hub = ThreadComm.Hub(4)
+    out = [None] * 4
+
+    def run(r):
+        e2, v2, _, c2 = _case("refine61")
+        e2.selection_max_fraction = 0.125
+        out[r] = _run_rank(e2, v2, None, c2, r, 4, comm=ThreadComm(hub, r))
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    assert all(o is not None and torch.equal(o, want) for o in out)
 
 
 def test_cases_exercise_what_they_claim():

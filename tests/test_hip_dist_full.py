@@ -178,7 +178,9 @@ def test_fullsize_sharded_selection_refinement_equals_serial():
     from tdc_video_amd.dist import ShardedVideoEncoder
     world, T = 4, 128
     engines = [_engine(T)[0] for _ in range(world)]
-    assert all(e.selection_eps == 1e-3 and "dino_precise" in e.towers for e in engines)
+    assert all(e.selection_eps == 1e-3 and "dino_precise" in e.towers and e.selection_max_fraction == 0.125 for e in engines)
+    for e in engines:
+        e.selection_max_fraction = 1.0          # the wide band of this video is the point here (the default caps it at T / 8 frames)
     info = {}
     want = engines[0].encode_video(_video(0, T, 384, 1234), _drift(0, T, T), (384, 384), budget_text_len=64, n_text_tokens=64,
                                    prompt_ids=PROMPT, frame_cap=T, info=info)
